@@ -1,0 +1,133 @@
+// Shared host/device helpers for libcvae_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace cvae {
+
+// ---- error plumbing: every extern "C" entry returns 0 or a negative code and leaves a
+// message for cvae_last_error().
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define CVAE_REQUIRE(cond, ...)                         \
+  do {                                                  \
+    if (!(cond)) {                                      \
+      ::cvae::set_error(__VA_ARGS__);                   \
+      return -1;                                        \
+    }                                                   \
+  } while (0)
+
+#define CVAE_LAUNCH_CHECK(name)                                        \
+  do {                                                                 \
+    int _rc = ::cvae::check_hip(hipGetLastError(), name);              \
+    if (_rc) return _rc;                                               \
+  } while (0)
+
+#define CVAE_TRY(expr)          \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc) return _rc;        \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_EXP = 3, ACT_CEGRAD = 4 };
+enum Cell { CELL_GRU = 0, CELL_LSTM = 1 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh through exp: accurate to ~1e-7 relative over the whole range (no fast-math shortcuts)
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_TANH: return tanhf_(v);
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_EXP: return expf(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- internal launchers shared between translation units (all enqueue on `s`) ----------
+struct GemmDesc {
+  int transA, transB;        // op(A) is MxK: transA=0 -> A[m*lda+k], 1 -> A[k*lda+m]
+  int M, N, K;               // op(B) is KxN: transB=0 -> B[k*ldb+n], 1 -> B[n*ldb+k]
+  const float* A; long lda;
+  const float* B; long ldb;
+  float* C; long ldc;
+  const float* bias;         // [N] or null
+  int act;                   // Act, applied after bias
+  int beta;                  // 0: overwrite, 1: C += result
+  // ACT_CEGRAD epilogue (projce backward): C = coef[m] * (exp(v - lse[m]) - (n == tgt[m]))
+  const float* row_lse; const float* row_coef; const int64_t* row_tgt;
+};
+int launch_gemm(const GemmDesc& d, hipStream_t s);
+
+// Few-row product with the K dimension split over the waves of a block (skinny.hip).
+enum SkinnyEpi { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2 };
+struct SkinnyArgs {
+  const float* A; long lda;            // [M,K], k contiguous
+  const float* B; long ldb; int transB;  // op(B) KxN: transB=1 -> B[n*ldb+k], 0 -> B[k*ldb+n]
+  int M, N, K;                         // N = output columns per gate group
+  int ngroups; long gstride;           // group g uses op(B) columns n + g*gstride
+  // EPI_LINEAR: C = act(A.op(B) + bias) (+ C)
+  float* C; long ldc; const float* bias; int act, beta;
+  // EPI_GRU / EPI_LSTM: N = H, groups = gates (r,z,n | i,f,g,o); A = h_prev
+  const float* xproj; long ldx; int xmod;  // x-side pre-activations of row r: xproj[(r % xmod)*ldx + g*H + n]
+  const float* xadd;                   // optional [M, G*H], added to xproj (time-invariant part)
+  const float* b_hh;                   // [G*H]
+  const float* h_prev; const float* c_prev;  // [M,H]
+  float* h_out; float* c_out;          // [M,H]
+  float* gates; long ldg;              // optional [M, 4H]: GRU r,z,n,(W_hn h + b_hn); LSTM i,f,g,o
+  const int64_t* lengths; int t;       // optional: row r is updated only while t < lengths[r]
+};
+int launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+
+
+// One direction of a 1-layer GRU/LSTM over T steps (rnn.hip).  State slots: hs/cs hold T+1
+// [R,H] slabs; forward reads slot t and writes slot t+1 (initial state in slot 0), reverse
+// walks t = T-1..0, reads slot t+1 and writes slot t (initial state in slot T).
+constexpr int SKINNY_MAX_ROWS = 256;
+struct RnnFwd {
+  int cell, T, R, H, reverse;
+  const float* xproj; int xmod;     // [T, xmod, G*H] x-side pre-activations (b_ih included); row r uses r % xmod
+  const float* xadd;                // [R, G*H] or null: time-invariant x-side part
+  const float* W_hh; const float* b_hh;
+  const float* h0; const float* c0; // [R,H] or null (zeros)
+  const int64_t* lengths;           // [R] or null: packed-sequence masking (row live iff t < len)
+  float* hs; float* cs;             // [(T+1),R,H]; cs null for GRU
+  float* gates;                     // [T,R,4H] or null (saved for backward)
+  float* hp_scratch;                // [R,G*H]; required when R > SKINNY_MAX_ROWS
+};
+int launch_rnn_forward(const RnnFwd& a, hipStream_t s);
+
+struct RnnBwd {
+  int cell, T, R, H, reverse;
+  const float* dhs;                 // [T,R,H] grad wrt each step's output, or null
+  const float* dh_last; const float* dc_last;  // [R,H] grad wrt the final state, or null
+  const float* hs; const float* cs; const float* gates;
+  const float* W_hh;
+  const int64_t* lengths;
+  float* dgx; float* dgh;           // [T,R,G*H] pre-activation grads, x side / h side (LSTM: dgh may be null = dgx)
+  float* dh0; float* dc0;           // [R,H] out: grad wrt the initial state
+  float* dh_tmp; float* dc_tmp;     // [R,H] scratch
+};
+int launch_rnn_backward(const RnnBwd& a, hipStream_t s);
+
+}  // namespace cvae

@@ -1,0 +1,178 @@
+// fp32 GEMM on the CDNA4 matrix cores (exact-f32 MFMA; gfx950 has no tf32/xf32 path and the
+// parity bar is 1e-4 relative, so bf16 operands are not an option for these contractions).
+//
+//   gemm_tiled   : LDS-staged, BMxBN block tile, v_mfma_f32_32x32x2_f32, 4 waves (2x2).
+//                  Used for every "many rows" contraction: input projections over T*B rows,
+//                  W_c, weight gradients, the logits chunk of the CE backward.
+//   gemm_skinny  : M <= 64 rows per block, operands straight from L2 to registers,
+//                  v_mfma_f32_16x16x4_f32, K split over the block's waves and reduced
+//                  through LDS.  Used for the per-timestep recurrent products at training
+//                  batch sizes (B=32), where one 32x32 tile per wave over the whole K would
+//                  serialise 256+ dependent MFMAs; also hosts the fused GRU/LSTM cell
+//                  epilogue (skinny.hip).
+#include "common.hpp"
+#include "tile.hpp"
+
+namespace cvae {
+
+struct TiledArgs {
+  const float* A; const float* B; float* C; const float* bias;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int act, beta;
+  int vecA, vecB;   // 16-byte vector loads allowed (base aligned, ld % 4 == 0)
+  int kchunk;       // K range per blockIdx.z (multiple of BK); gridDim.z > 1 -> atomic accumulate
+  const float* row_lse; const float* row_coef; const int64_t* row_tgt;   // ACT_CEGRAD
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
+  // op(A) rows = m: stored [m][k] when !TA (k contiguous) ; op(B) "rows" = n: stored [n][k] when TB
+  using LA = TileLoader<BM, !TA>;
+  using LB = TileLoader<BN, TB>;
+  constexpr int MI = BM / 64, NI = BN / 64;
+  __shared__ __attribute__((aligned(16))) float As[BK * LA::LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LB::LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  LA la; LB lb;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  la.load(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA, tid);
+  lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB, tid);
+  la.store(As, tid);
+  lb.store(Bs, tid);
+  __syncthreads();
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, p.vecA, tid);
+      lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, p.vecB, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = As[(kk + lhi) * LA::LD + wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bs[(kk + lhi) * LB::LD + wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      la.store(As, tid);
+      lb.store(Bs, tid);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn0 + j * 32 + l31;
+      if (n >= p.N) continue;
+      const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m < p.M) {
+          float v = acc[i][j][r] + bv;
+          float* c = p.C + (long)m * p.ldc + n;
+          if (gridDim.z > 1) {
+            atomicAdd(c, v);          // split-K: C was zeroed (or holds the beta term) by the host
+          } else {
+            if (p.act == ACT_CEGRAD)  // d(loss)/d(logit) = coef * (softmax - onehot)
+              v = p.row_coef[m] * (expf(v - p.row_lse[m]) - ((int64_t)n == p.row_tgt[m] ? 1.f : 0.f));
+            else
+              v = apply_act(v, p.act);
+            if (p.beta) v += *c;
+            *c = v;
+          }
+        }
+      }
+    }
+}
+
+template <int BM, int BN>
+static int launch_tiled(const GemmDesc& d, hipStream_t s) {
+  TiledArgs a;
+  a.A = d.A; a.B = d.B; a.C = d.C; a.bias = d.bias;
+  a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc;
+  a.M = d.M; a.N = d.N; a.K = d.K; a.act = d.act; a.beta = d.beta;
+  a.vecA = aligned16(d.A) && (d.lda % 4 == 0);
+  a.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
+  a.row_lse = d.row_lse; a.row_coef = d.row_coef; a.row_tgt = d.row_tgt;
+  // split-K when the output has too few tiles to fill 256 CUs and K is long
+  const long tiles = (long)cdiv(d.N, BN) * cdiv(d.M, BM);
+  int ksplit = 1;
+  if (d.act == ACT_NONE && tiles < 128 && d.K >= 1024) {
+    ksplit = (int)((512 + tiles - 1) / tiles);
+    const int maxs = d.K / 256;
+    if (ksplit > maxs) ksplit = maxs;
+    if (ksplit < 1) ksplit = 1;
+  }
+  a.kchunk = ((d.K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+  ksplit = (d.K + a.kchunk - 1) / a.kchunk;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 1 && !d.beta) {
+    if (d.ldc == d.N) {
+      CVAE_TRY(check_hip(hipMemsetAsync(d.C, 0, (size_t)d.M * d.N * sizeof(float), s), "gemm split-K memset"));
+    } else {
+      CVAE_TRY(check_hip(hipMemset2DAsync(d.C, d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), d.M, s),
+                         "gemm split-K memset2D"));
+    }
+  }
+  dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), ksplit);
+  if (!d.transA && d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a);
+  else if (!d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a);
+  else if (d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, a);
+  CVAE_LAUNCH_CHECK("gemm_tiled");
+  return 0;
+}
+
+int launch_gemm(const GemmDesc& d, hipStream_t s) {
+  CVAE_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dimension");
+  if (d.M == 0 || d.N == 0) return 0;
+  CVAE_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
+  CVAE_REQUIRE(d.act != ACT_CEGRAD || (d.row_lse && d.row_coef && d.row_tgt && !d.beta), "gemm: CE-grad epilogue operands missing");
+  if (d.K == 0) {
+    CVAE_REQUIRE(d.act == ACT_NONE && !d.bias, "gemm: K == 0 with an epilogue");
+    if (!d.beta) CVAE_TRY(check_hip(hipMemset2DAsync(d.C, d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), d.M, s), "gemm K=0 memset"));
+    return 0;
+  }
+  CVAE_REQUIRE(d.lda >= (d.transA ? d.M : d.K) && d.ldb >= (d.transB ? d.K : d.N) && d.ldc >= d.N,
+               "gemm: leading dimension smaller than the row length");
+  // Skinny path: few rows, plain A, K long enough to be worth splitting over waves.
+  if (!d.transA && d.M <= 64 && d.K >= 64 && d.act != ACT_CEGRAD) {
+    SkinnyArgs a = {};
+    a.A = d.A; a.lda = d.lda; a.B = d.B; a.ldb = d.ldb; a.transB = d.transB;
+    a.M = d.M; a.N = d.N; a.K = d.K; a.ngroups = 1; a.gstride = 0;
+    a.C = d.C; a.ldc = d.ldc; a.bias = d.bias; a.act = d.act; a.beta = d.beta;
+    return launch_skinny(a, EPI_LINEAR, s);
+  }
+  const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+  if (tiles128 >= 192) return launch_tiled<128, 128>(d, s);
+  return launch_tiled<64, 64>(d, s);
+}
+
+}  // namespace cvae
