@@ -1,0 +1,411 @@
+// extern "C" surface of libcvae_hip (declared in include/cvae_hip.h) and the host-side
+// sequencing of the kernels: which GEMM feeds which recurrence, in what layout.
+#include "../../include/cvae_hip.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace cvae {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return -2;
+}
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int gates_of(int cell) { return cell == CELL_GRU ? 3 : 4; }
+
+static int linear_nt(const float* x, const float* W, long ldw, const float* b, int act, int M, int N, int K,
+                     float* y, hipStream_t s) {
+  GemmDesc d = {};
+  d.transA = 0; d.transB = 1; d.M = M; d.N = N; d.K = K;
+  d.A = x; d.lda = K; d.B = W; d.ldb = ldw; d.C = y; d.ldc = N; d.bias = b; d.act = act;
+  return launch_gemm(d, s);
+}
+
+// dW[N,K] = dy[M,N]^T . x[M,K]
+static int grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
+                       int beta, hipStream_t s) {
+  GemmDesc d = {};
+  d.transA = 1; d.transB = 0; d.M = N; d.N = K; d.K = M;
+  d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dW; d.ldc = K; d.beta = beta;
+  return launch_gemm(d, s);
+}
+
+// dx[M,K] = dy[M,N] . W[N,K]
+static int grad_input(const float* dy, long lddy, const float* W, long ldw, int M, int N, int K, float* dx,
+                      long lddx, int beta, hipStream_t s) {
+  GemmDesc d = {};
+  d.transA = 0; d.transB = 0; d.M = M; d.N = K; d.K = N;
+  d.A = dy; d.lda = lddy; d.B = W; d.ldb = ldw; d.C = dx; d.ldc = lddx; d.beta = beta;
+  return launch_gemm(d, s);
+}
+
+static int grad_bias(const float* dy, int M, int N, long ld, float* db, hipStream_t s) {
+  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s), "bias grad memset"));
+  return launch_colsum_acc(dy, M, N, ld, db, s);
+}
+
+}  // namespace cvae
+
+using namespace cvae;
+
+extern "C" {
+
+int cvae_version(void) { return 100; }
+const char* cvae_last_error(void) { return g_err; }
+
+int cvae_init(int device) {
+  int n = 0;
+  CVAE_TRY(check_hip(hipGetDeviceCount(&n), "hipGetDeviceCount"));
+  CVAE_REQUIRE(device >= 0 && device < n, "cvae_init: device %d out of range (%d visible)", device, n);
+  hipDeviceProp_t prop;
+  CVAE_TRY(check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
+  CVAE_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+               "cvae_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+               prop.gcnArchName);
+  CVAE_TRY(check_hip(hipSetDevice(device), "hipSetDevice"));
+  return 0;
+}
+
+int cvae_pack_batch(const int64_t* raw_flat, const int64_t* raw_offsets, int B, int max_len, int width,
+                    int64_t pad, int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out,
+                    int64_t* len, void* stream) {
+  return launch_pack_batch(raw_flat, raw_offsets, B, max_len, width, pad, go, eos, bare, go_out, eos_out, len,
+                           S(stream));
+}
+
+int cvae_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, void* stream) {
+  return launch_sort_resort(len, B, s_idx, res_idx, S(stream));
+}
+
+int cvae_gemm(int transA, int transB, int M, int N, int K, const float* A, int64_t lda, const float* B,
+              int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int beta, void* stream) {
+  CVAE_REQUIRE(act >= ACT_NONE && act <= ACT_EXP, "cvae_gemm: bad act %d", act);
+  GemmDesc d = {};
+  d.transA = transA; d.transB = transB; d.M = M; d.N = N; d.K = K;
+  d.A = A; d.lda = lda; d.B = B; d.ldb = ldb; d.C = C; d.ldc = ldc; d.bias = bias; d.act = act; d.beta = beta;
+  return launch_gemm(d, S(stream));
+}
+
+int cvae_linear_forward(const float* x, const float* W, const float* b, int act, int M, int N, int K, float* y,
+                        void* stream) {
+  CVAE_REQUIRE(act >= ACT_NONE && act <= ACT_EXP, "linear_forward: bad act %d", act);
+  return linear_nt(x, W, K, b, act, M, N, K, y, S(stream));
+}
+
+int cvae_linear_backward(const float* x, const float* W, const float* y, const float* dy, int act, int M, int N,
+                         int K, float* dx, float* dW, float* db, float* scratch, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(x && W && dy && dW && db, "linear_backward: null operand");
+  const float* dpre = dy;
+  if (act != ACT_NONE) {
+    CVAE_REQUIRE(y && scratch, "linear_backward: act needs y and scratch");
+    CVAE_TRY(launch_act_bwd((long)M * N, act, y, dy, scratch, s));
+    dpre = scratch;
+  }
+  CVAE_TRY(grad_weight(dpre, N, x, K, M, N, K, dW, 0, s));
+  CVAE_TRY(grad_bias(dpre, M, N, N, db, s));
+  if (dx) CVAE_TRY(grad_input(dpre, N, W, K, M, N, K, dx, K, 0, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ encoder
+int cvae_encoder_forward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
+                         const float* emb, const float* mask, const int64_t* mask_rows, const float* const* w,
+                         float* X, float* xproj, float* hs, float* cs, float* gates, float* last, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_forward: bad cell");
+  CVAE_REQUIRE(B > 0 && L > 0 && E > 0 && H > 0 && V > 0, "encoder_forward: bad shape B=%d L=%d E=%d H=%d", B, L, E, H);
+  CVAE_REQUIRE(B <= SKINNY_MAX_ROWS, "encoder_forward: B=%d > %d not supported", B, SKINNY_MAX_ROWS);
+  CVAE_REQUIRE(ids && len && emb && w && X && xproj && hs && last, "encoder_forward: null operand");
+  CVAE_REQUIRE(cell == CELL_GRU || cs, "encoder_forward: LSTM needs cs");
+  const int G = gates_of(cell);
+  CVAE_TRY(launch_embed(L, B, E, 0, 0, ids, B, emb, nullptr, mask, mask_rows, X, s));
+  for (int d = 0; d < 2; ++d) {
+    const float* W_ih = w[4 * d + 0]; const float* W_hh = w[4 * d + 1];
+    const float* b_ih = w[4 * d + 2]; const float* b_hh = w[4 * d + 3];
+    float* xp = xproj + (long)d * L * B * G * H;
+    CVAE_TRY(linear_nt(X, W_ih, E, b_ih, ACT_NONE, L * B, G * H, E, xp, s));
+    RnnFwd f = {};
+    f.cell = cell; f.T = L; f.R = B; f.H = H; f.reverse = d;
+    f.xproj = xp; f.xmod = B; f.W_hh = W_hh; f.b_hh = b_hh; f.lengths = len;
+    f.hs = hs + (long)d * (L + 1) * B * H;
+    f.cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
+    f.gates = gates ? gates + (long)d * L * B * 4 * H : nullptr;
+    CVAE_TRY(launch_rnn_forward(f, s));
+    const float* fin = f.hs + (long)(d ? 0 : L) * B * H;
+    CVAE_TRY(launch_copy_cols(B, H, fin, H, 0, last, 2L * H, d * H, s));
+  }
+  return 0;
+}
+
+int64_t cvae_encoder_backward_scratch(int cell, int B, int L, int E, int H) {
+  const int64_t G = gates_of(cell);
+  //   dgx, dgh [L,B,G*H] + dX [L,B,E] + dh_last, dh0, dh_tmp, dc0, dc_tmp [B,H]
+  return 2 * (int64_t)L * B * G * H + (int64_t)L * B * E + 5 * (int64_t)B * H;
+}
+
+int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
+                          const float* mask, const int64_t* mask_rows, const float* const* w, const float* X,
+                          const float* hs, const float* cs, const float* gates, const float* dlast,
+                          float* const* dw, float* demb, float* scratch, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_backward: bad cell");
+  CVAE_REQUIRE(B > 0 && L > 0 && E > 0 && H > 0 && V > 0, "encoder_backward: bad shape");
+  CVAE_REQUIRE(ids && len && w && X && hs && gates && dlast && dw && demb && scratch, "encoder_backward: null operand");
+  const int G = gates_of(cell);
+  const long LBG = (long)L * B * G * H, BH = (long)B * H;
+  float* dgx = scratch;
+  float* dgh = dgx + LBG;
+  float* dX = dgh + LBG;
+  float* dh_last = dX + (long)L * B * E;
+  float* dh0 = dh_last + BH; float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+  for (int d = 0; d < 2; ++d) {
+    const float* W_ih = w[4 * d + 0]; const float* W_hh = w[4 * d + 1];
+    CVAE_TRY(launch_copy_cols(B, H, dlast, 2L * H, d * H, dh_last, H, 0, s));
+    const float* hs_d = hs + (long)d * (L + 1) * B * H;
+    RnnBwd r = {};
+    r.cell = cell; r.T = L; r.R = B; r.H = H; r.reverse = d;
+    r.dh_last = dh_last; r.hs = hs_d; r.cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
+    r.gates = gates + (long)d * L * B * 4 * H; r.W_hh = W_hh; r.lengths = len;
+    r.dgx = dgx; r.dgh = (cell == CELL_GRU) ? dgh : nullptr;
+    r.dh0 = dh0; r.dc0 = dc0; r.dh_tmp = dh_tmp; r.dc_tmp = dc_tmp;
+    CVAE_TRY(launch_rnn_backward(r, s));
+    const float* dgh_eff = (cell == CELL_GRU) ? dgh : dgx;
+    // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
+    const float* hprev = hs_d + (d ? BH : 0);
+    CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s));
+    CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
+    CVAE_TRY(grad_weight(dgx, (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s));
+    CVAE_TRY(grad_bias(dgx, L * B, G * H, (long)G * H, dw[4 * d + 2], s));
+    CVAE_TRY(grad_input(dgx, (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s));
+  }
+  CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ids, dX, mask, mask_rows, demb, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ decoder
+int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd, int64_t V, const float* init,
+                         const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
+                         const float* const* w, float* X, float* xproj, float* xadd, float* hp, float* hs,
+                         float* cs, float* gates, float* hdrop, float* final, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_forward: bad cell");
+  CVAE_REQUIRE(B > 0 && R > 0 && T > 0 && E > 0 && Hd > 0 && V > 0 && R % B == 0,
+               "decoder_forward: bad shape B=%d R=%d T=%d E=%d Hd=%d", B, R, T, E, Hd);
+  CVAE_REQUIRE(init && go && emb && w && X && xproj && hs && final, "decoder_forward: null operand");
+  CVAE_REQUIRE(cell == CELL_GRU || cs, "decoder_forward: LSTM needs cs");
+  const int G = gates_of(cell);
+  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* b_ih = w[2]; const float* b_hh = w[3];
+  const float* W_c = w[4]; const float* b_c = w[5];
+  const long RH = (long)R * Hd, GH = (long)G * Hd;
+  const float* hout;     // [T,R,Hd] input of W_c
+  if (train) {
+    CVAE_REQUIRE(R == B, "decoder_forward(train): R must equal B");
+    CVAE_REQUIRE(gates && (mask_out == nullptr || hdrop), "decoder_forward(train): gates / hdrop missing");
+    CVAE_REQUIRE(R <= SKINNY_MAX_ROWS || hp, "decoder_forward: hp scratch required for R > %d", SKINNY_MAX_ROWS);
+    CVAE_TRY(launch_embed(T, B, E, 1, 1, go, B, emb, init, mask_in, nullptr, X, s));
+    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, (T + 1) * B, (int)GH, 2 * E, xproj, s));
+    RnnFwd f = {};
+    f.cell = cell; f.T = T + 1; f.R = R; f.H = Hd; f.xproj = xproj; f.xmod = R;
+    f.W_hh = W_hh; f.b_hh = b_hh; f.hs = hs; f.cs = cs; f.gates = gates; f.hp_scratch = hp;
+    CVAE_TRY(launch_rnn_forward(f, s));
+    hout = hs + 2 * RH;
+    if (mask_out) {
+      CVAE_TRY(launch_mul((long)T * RH, hout, mask_out, hdrop, s));
+      hout = hdrop;
+    }
+  } else {
+    CVAE_REQUIRE(!mask_in && !mask_out, "decoder_forward(eval): dropout masks given");
+    CVAE_REQUIRE(xadd, "decoder_forward(eval): xadd missing");
+    CVAE_REQUIRE(R <= SKINNY_MAX_ROWS || hp, "decoder_forward: hp scratch required for R > %d", SKINNY_MAX_ROWS);
+    // x-side pre-activations, de-duplicated:
+    //   steps 1..T : W_ih[:, :E] emb(go_t) + b_ih (per sentence)  +  W_ih[:, E:] init (per row, time-invariant)
+    //   step 0     : W_ih[:, :E] init + b_ih (per row)            +  the same time-invariant part
+    float* xinit = xadd;            // [R, G*Hd]
+    float* x0 = xadd + (long)R * GH;  // [R, G*Hd]
+    CVAE_TRY(launch_embed(T, B, E, 0, 0, go, B, emb, nullptr, nullptr, nullptr, X, s));
+    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, T * B, (int)GH, E, xproj, s));
+    CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, R, (int)GH, E, xinit, s));
+    CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, R, (int)GH, E, x0, s));
+    RnnFwd f0 = {};
+    f0.cell = cell; f0.T = 1; f0.R = R; f0.H = Hd; f0.xproj = x0; f0.xmod = R; f0.xadd = xinit;
+    f0.W_hh = W_hh; f0.b_hh = b_hh; f0.hs = hs; f0.cs = cs; f0.hp_scratch = hp;
+    CVAE_TRY(launch_rnn_forward(f0, s));
+    RnnFwd f = f0;
+    f.T = T; f.xproj = xproj; f.xmod = B; f.hs = hs + RH; f.cs = cs ? cs + RH : nullptr;
+    f.init_in_place = 1;                               // slot 0 of this view = h_0 from the prefix step
+    CVAE_TRY(launch_rnn_forward(f, s));
+    hout = hs + 2 * RH;
+  }
+  CVAE_TRY(linear_nt(hout, W_c, Hd, b_c, ACT_TANH, T * R, E, Hd, final, s));
+  return 0;
+}
+
+int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd) {
+  const int64_t G = gates_of(cell), T1 = T + 1;
+  // dpre [T,B,E] + dhs [(T+1),B,Hd] + dgx,dgh [(T+1),B,G*Hd] + dX [(T+1),B,2E] + 4 x [B,Hd]
+  return (int64_t)T * B * E + T1 * B * Hd + 2 * T1 * B * G * Hd + T1 * B * 2 * E + 4 * (int64_t)B * Hd;
+}
+
+int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                          const float* mask_in, const float* mask_out, const float* const* w, const float* X,
+                          const float* hs, const float* cs, const float* gates, const float* hdrop,
+                          const float* final, const float* dfinal, float* dinit, float* const* dw, float* demb,
+                          float* scratch, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_backward: bad cell");
+  CVAE_REQUIRE(B > 0 && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward: bad shape");
+  CVAE_REQUIRE(go && w && X && hs && gates && final && dfinal && dinit && dw && demb && scratch,
+               "decoder_backward: null operand");
+  CVAE_REQUIRE(!mask_out || hdrop, "decoder_backward: hdrop missing");
+  const int G = gates_of(cell), T1 = T + 1;
+  const long BH = (long)B * Hd, GH = (long)G * Hd;
+  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* W_c = w[4];
+  float* dpre = scratch;
+  float* dhs = dpre + (long)T * B * E;
+  float* dgx = dhs + (long)T1 * BH;
+  float* dgh = dgx + (long)T1 * B * GH;
+  float* dX = dgh + (long)T1 * B * GH;
+  float* dh0 = dX + (long)T1 * B * 2 * E;
+  float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+  const float* hout = mask_out ? hdrop : hs + 2 * BH;
+  // final = tanh(hout W_c^T + b_c)
+  CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, final, dfinal, dpre, s));
+  CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, dw[4], 0, s));
+  CVAE_TRY(grad_bias(dpre, T * B, E, E, dw[5], s));
+  CVAE_TRY(check_hip(hipMemsetAsync(dhs, 0, (size_t)BH * sizeof(float), s), "dhs[0] memset"));
+  CVAE_TRY(grad_input(dpre, E, W_c, Hd, T * B, E, Hd, dhs + BH, Hd, 0, s));
+  if (mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, mask_out, dhs + BH, s));
+  RnnBwd r = {};
+  r.cell = cell; r.T = T1; r.R = B; r.H = Hd; r.reverse = 0;
+  r.dhs = dhs; r.hs = hs; r.cs = cs; r.gates = gates; r.W_hh = W_hh;
+  r.dgx = dgx; r.dgh = (cell == CELL_GRU) ? dgh : nullptr;
+  r.dh0 = dh0; r.dc0 = dc0; r.dh_tmp = dh_tmp; r.dc_tmp = dc_tmp;
+  CVAE_TRY(launch_rnn_backward(r, s));
+  const float* dgh_eff = (cell == CELL_GRU) ? dgh : dgx;
+  CVAE_TRY(grad_weight(dgh_eff, GH, hs, Hd, T1 * B, (int)GH, Hd, dw[1], 0, s));
+  CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, dw[3], s));
+  CVAE_TRY(grad_weight(dgx, GH, X, 2L * E, T1 * B, (int)GH, 2 * E, dw[0], 0, s));
+  CVAE_TRY(grad_bias(dgx, T1 * B, (int)GH, GH, dw[2], s));
+  CVAE_TRY(grad_input(dgx, GH, W_ih, 2L * E, T1 * B, (int)GH, 2 * E, dX, 2L * E, 0, s));
+  CVAE_TRY(launch_dec_dinit(T, B, E, dX, mask_in, dinit, s));
+  CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX, mask_in, nullptr, demb, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ projection + CE
+int64_t cvae_projce_workspace(int64_t N, int64_t V) { return projce_workspace_floats((int)N, (int)V); }
+
+int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                        int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent, float* ws,
+                        void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V < (1LL << 31), "projce_forward: bad shape");
+  CVAE_TRY(launch_projce_forward(final, W, b, tgt, pad, T * R, E, (int)V, loss_row, lse, ws, s));
+  if (sent) CVAE_TRY(launch_sum_time(loss_row, T, R, sent, s));
+  return 0;
+}
+
+int64_t cvae_projce_backward_workspace(int64_t N, int64_t V) {
+  return projce_bwd_workspace_floats((int)N, (int)V) + N;   // + broadcast of gsent over time
+}
+
+int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                         const float* lse, const float* gsent, int T, int R, int E, int64_t V, float* dfinal,
+                         float* dW, float* db, float* ws, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V < (1LL << 31), "projce_backward: bad shape");
+  CVAE_REQUIRE(gsent && ws && dW && db, "projce_backward: null operand");
+  const int N = T * R;
+  float* grow = ws;
+  CVAE_TRY(launch_bcast_time(gsent, T, R, grow, s));
+  CVAE_TRY(check_hip(hipMemsetAsync(dW, 0, (size_t)V * E * sizeof(float), s), "dW memset"));
+  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)V * sizeof(float), s), "db memset"));
+  return launch_projce_backward(final, W, b, tgt, pad, lse, grow, N, E, (int)V, dfinal, dW, db, ws + N, s);
+}
+
+int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream) {
+  CVAE_REQUIRE(B > 0 && R % B == 0, "targets_time_major: R must be a multiple of B");
+  return launch_targets_tm(eos, B, T, R, tgt_tm, S(stream));
+}
+
+int cvae_logits(const float* final, const float* W, const float* b, int T, int B, int E, int64_t V, float* tmp,
+                float* logits, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_TRY(linear_nt(final, W, E, b, ACT_NONE, T * B, (int)V, E, tmp, s));
+  return launch_logits_bt(T, B, (long)V, tmp, logits, s);
+}
+
+// ------------------------------------------------------------------------------ latent space
+int cvae_reparam_forward(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
+                         void* stream) {
+  CVAE_REQUIRE(mu && sigma && eps && z, "reparam_forward: null operand");
+  return launch_reparam_fwd(mu, sigma, eps, n, B, Z, z, S(stream));
+}
+int cvae_reparam_backward(const float* dz, const float* eps, int B, int Z, float* dmu, float* dsigma,
+                          void* stream) {
+  CVAE_REQUIRE(dz && eps && dmu && dsigma, "reparam_backward: null operand");
+  return launch_reparam_bwd(dz, eps, B, Z, dmu, dsigma, S(stream));
+}
+int cvae_kl_forward(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, int B, int Z,
+                    float* kl, void* stream) {
+  CVAE_REQUIRE(mu && sigma && kl, "kl_forward: null operand");
+  return launch_kl_fwd(mu, sigma, mu_p, sigma_p, B, Z, kl, S(stream));
+}
+int cvae_kl_backward(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
+                     const float* gkl, int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p,
+                     void* stream) {
+  CVAE_REQUIRE(mu && sigma && gkl && dmu && dsigma, "kl_backward: null operand");
+  return launch_kl_bwd(mu, sigma, mu_p, sigma_p, gkl, B, Z, dmu, dsigma, dmu_p, dsigma_p, S(stream));
+}
+int cvae_couple_forward(const float* init, const float* init_c, int B, int E, int Z, int euclid, float* d,
+                        float* loss, void* stream) {
+  CVAE_REQUIRE(init && init_c && d && loss, "couple_forward: null operand");
+  return launch_couple_fwd(init, init_c, B, E, Z, euclid, d, loss, S(stream));
+}
+int cvae_couple_backward(const float* init, const float* init_c, const float* d, const float* gloss, int B,
+                         int E, int Z, int euclid, float* dinit, void* stream) {
+  CVAE_REQUIRE(init && init_c && d && gloss && dinit, "couple_backward: null operand");
+  return launch_couple_bwd(init, init_c, d, gloss, B, E, Z, euclid, dinit, S(stream));
+}
+int cvae_iw_reduce(const float* z, const float* xent, const float* mu, const float* sigma, const float* mu_p,
+                   const float* sigma_p, int K, int B, int Z, float* nll, float* kl, float* xent_mean,
+                   void* stream) {
+  CVAE_REQUIRE(z && xent && mu && sigma && nll && kl && xent_mean, "iw_reduce: null operand");
+  return launch_iw_reduce(z, xent, mu, sigma, mu_p, sigma_p, K, B, Z, nll, kl, xent_mean, S(stream));
+}
+int cvae_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* ws, float* mi,
+               void* stream) {
+  CVAE_REQUIRE(z && mu && sigma && ws && mi, "mi: null operand");
+  return launch_mi(z, mu, sigma, K, B, Z, ws, ws + (long)K * B, mi, S(stream));
+}
+int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
+                   int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
+                   float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
+                   void* stream) {
+  return launch_clip_adam(params, grads, m, v, n, alias_off, alias_n, alias_mult, max_norm, lr, beta1, beta2, eps,
+                          step_other, step_alias, sumsq, norm_out, S(stream));
+}
+int cvae_sum_time(const float* x, int T, int R, float* out, void* stream) {
+  return launch_sum_time(x, T, R, out, S(stream));
+}
+int cvae_axpy(const float* x, float a, int64_t n, float* y, void* stream) {
+  return launch_axpy(n, x, a, y, S(stream));
+}
+
+}  // extern "C"

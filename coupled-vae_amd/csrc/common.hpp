@@ -110,6 +110,7 @@ struct RnnFwd {
   const float* xadd;                // [R, G*H] or null: time-invariant x-side part
   const float* W_hh; const float* b_hh;
   const float* h0; const float* c0; // [R,H] or null (zeros)
+  int init_in_place;                // 1: the initial slot of hs/cs already holds the state
   const int64_t* lengths;           // [R] or null: packed-sequence masking (row live iff t < len)
   float* hs; float* cs;             // [(T+1),R,H]; cs null for GRU
   float* gates;                     // [T,R,4H] or null (saved for backward)

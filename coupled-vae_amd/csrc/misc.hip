@@ -1,0 +1,611 @@
+// Bandwidth-shaped kernels of the path: batch layout (a1/a2), embedding gather / scatter,
+// dropout-mask application, reparameterisation, KL, coupling loss, IW log-sum-exp, the MI
+// pairwise density, and the clip + Adam step.  All are one-pass, coalesced along the
+// fastest dimension; reductions use 64-wide wave shuffles.
+#include "common.hpp"
+#include "misc.hpp"
+#include <math.h>
+
+namespace cvae {
+
+#define GRID1D(n) dim3(cdiv((n), 256)), dim3(256)
+#define IDX1D(n)                                                      \
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       \
+  if (idx >= (long)(n)) return;
+
+// ------------------------------------------------------------------ a1 / a2
+__global__ void pack_batch_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ off, int B,
+                                  int max_len, int width, int64_t pad, int64_t go, int64_t eos,
+                                  int64_t* __restrict__ bare, int64_t* __restrict__ go_out,
+                                  int64_t* __restrict__ eos_out, int64_t* __restrict__ len) {
+  IDX1D((long)B * (width + 1));
+  const int b = (int)(idx / (width + 1)), j = (int)(idx % (width + 1));
+  const int64_t beg = off[b];
+  int64_t l = off[b + 1] - beg;
+  if (l > max_len) l = max_len;
+  if (j == 0) len[b] = l;
+  // bare[j] = id_j | pad ; go[j] = go, id_{j-1} | pad ; eos[j] = id_j, eos at j == l | pad
+  if (j < width) bare[(long)b * width + j] = j < l ? flat[beg + j] : pad;
+  go_out[(long)b * (width + 1) + j] = j == 0 ? go : (j - 1 < l ? flat[beg + j - 1] : pad);
+  eos_out[(long)b * (width + 1) + j] = j < l ? flat[beg + j] : (j == l ? eos : pad);
+}
+
+int launch_pack_batch(const int64_t* flat, const int64_t* off, int B, int max_len, int width, int64_t pad,
+                      int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out, int64_t* len,
+                      hipStream_t s) {
+  CVAE_REQUIRE(B >= 0 && max_len >= 0 && width >= 0 && width <= max_len, "pack_batch: bad shape");
+  if (B == 0) return 0;
+  CVAE_REQUIRE(flat && off && bare && go_out && eos_out && len, "pack_batch: null operand");
+  hipLaunchKernelGGL(pack_batch_kernel, GRID1D((long)B * (width + 1)), 0, s, flat, off, B, max_len, width, pad, go,
+                     eos, bare, go_out, eos_out, len);
+  CVAE_LAUNCH_CHECK("pack_batch_kernel");
+  return 0;
+}
+
+// stable descending rank: pos(i) = #{j : len[j] > len[i]} + #{j < i : len[j] == len[i]}
+__global__ void sort_resort_kernel(const int64_t* __restrict__ len, int B, int64_t* __restrict__ s_idx,
+                                   int64_t* __restrict__ res_idx) {
+  IDX1D(B);
+  const int64_t li = len[idx];
+  int pos = 0;
+  for (int j = 0; j < B; ++j) {
+    const int64_t lj = len[j];
+    pos += (lj > li) || (lj == li && j < idx);
+  }
+  res_idx[idx] = pos;
+  s_idx[pos] = idx;
+}
+
+int launch_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, hipStream_t s) {
+  if (B == 0) return 0;
+  CVAE_REQUIRE(len && s_idx && res_idx, "sort_resort: null operand");
+  hipLaunchKernelGGL(sort_resort_kernel, GRID1D(B), 0, s, len, B, s_idx, res_idx);
+  CVAE_LAUNCH_CHECK("sort_resort_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ embedding gather / scatter
+// out[(slot0 + t), r, 0:E]   = emb[ids[b*T + t]] * mask
+// out[(slot0 + t), r, E:2E]  = cond[r] * mask                      (when cond != null, W = 2E)
+// prefix slot (slot0 == 1):  out[0, r, :] = [cond[r], cond[r]]
+__global__ void embed_kernel(int T, int R, int E, int W, int slot0, const int64_t* __restrict__ ids, int Bids,
+                             const float* __restrict__ emb, const float* __restrict__ cond,
+                             const float* __restrict__ mask, const int64_t* __restrict__ mask_rows,
+                             float* __restrict__ out) {
+  IDX1D((long)(T + slot0) * R * W);
+  const int e = (int)(idx % W);
+  const int r = (int)((idx / W) % R);
+  const int slot = (int)(idx / ((long)W * R));
+  float v;
+  if (slot < slot0) {
+    v = cond[(long)r * E + (e < E ? e : e - E)];
+  } else {
+    const int t = slot - slot0;
+    if (e < E) v = emb[ids[(long)(r % Bids) * T + t] * E + e];
+    else v = cond[(long)r * E + (e - E)];
+    if (mask) {
+      const long mr = mask_rows ? mask_rows[r] : r;
+      v *= mask[((long)t * R + mr) * W + e];
+    }
+  }
+  out[idx] = v;
+}
+
+int launch_embed(int T, int R, int E, int with_cond, int prefix, const int64_t* ids, int Bids, const float* emb,
+                 const float* cond, const float* mask, const int64_t* mask_rows, float* out, hipStream_t s) {
+  const int W = with_cond ? 2 * E : E;
+  CVAE_REQUIRE(!prefix || with_cond, "embed: a prefix slot needs cond");
+  CVAE_REQUIRE(ids && emb && out && (!with_cond || cond) && Bids > 0, "embed: null operand");
+  const long n = (long)(T + (prefix ? 1 : 0)) * R * W;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(embed_kernel, GRID1D(n), 0, s, T, R, E, W, prefix ? 1 : 0, ids, Bids, emb, cond, mask,
+                     mask_rows, out);
+  CVAE_LAUNCH_CHECK("embed_kernel");
+  return 0;
+}
+
+// demb[ids[b,t], e] += dX[slot0 + t, b, e] * mask       (float atomics: rows repeat)
+__global__ void embed_scatter_kernel(int T, int B, int E, int W, int slot0, const int64_t* __restrict__ ids,
+                                     const float* __restrict__ dX, const float* __restrict__ mask,
+                                     const int64_t* __restrict__ mask_rows, float* __restrict__ demb) {
+  IDX1D((long)T * B * E);
+  const int e = (int)(idx % E);
+  const int b = (int)((idx / E) % B);
+  const int t = (int)(idx / ((long)E * B));
+  float v = dX[((long)(t + slot0) * B + b) * W + e];
+  if (mask) {
+    const long mr = mask_rows ? mask_rows[b] : b;
+    v *= mask[((long)t * B + mr) * W + e];
+  }
+  atomicAdd(demb + ids[(long)b * T + t] * E + e, v);
+}
+
+int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* ids, const float* dX,
+                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s) {
+  if ((long)T * B * E == 0) return 0;
+  hipLaunchKernelGGL(embed_scatter_kernel, GRID1D((long)T * B * E), 0, s, T, B, E, W, slot0, ids, dX, mask,
+                     mask_rows, demb);
+  CVAE_LAUNCH_CHECK("embed_scatter_kernel");
+  return 0;
+}
+
+// dinit[b,e] = dX[0,b,e] + dX[0,b,E+e] + sum_t dX[1+t,b,E+e] * mask[t,b,E+e]
+__global__ void dec_dinit_kernel(int T, int B, int E, const float* __restrict__ dX, const float* __restrict__ mask,
+                                 float* __restrict__ dinit) {
+  IDX1D((long)B * E);
+  const int e = (int)(idx % E), b = (int)(idx / E);
+  const long W = 2L * E;
+  float acc = dX[(long)b * W + e] + dX[(long)b * W + E + e];
+  for (int t = 0; t < T; ++t) {
+    float v = dX[((long)(t + 1) * B + b) * W + E + e];
+    if (mask) v *= mask[((long)t * B + b) * W + E + e];
+    acc += v;
+  }
+  dinit[idx] = acc;
+}
+
+int launch_dec_dinit(int T, int B, int E, const float* dX, const float* mask, float* dinit, hipStream_t s) {
+  hipLaunchKernelGGL(dec_dinit_kernel, GRID1D((long)B * E), 0, s, T, B, E, dX, mask, dinit);
+  CVAE_LAUNCH_CHECK("dec_dinit_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ elementwise helpers
+__global__ void mul_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o) {
+  IDX1D(n);
+  o[idx] = b ? a[idx] * b[idx] : a[idx];
+}
+int launch_mul(long n, const float* a, const float* b, float* o, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mul_kernel, GRID1D(n), 0, s, n, a, b, o);
+  CVAE_LAUNCH_CHECK("mul_kernel");
+  return 0;
+}
+
+__global__ void act_bwd_kernel(long n, int act, const float* __restrict__ y, const float* __restrict__ dy,
+                               float* __restrict__ o) {
+  IDX1D(n);
+  const float yv = y[idx], g = dy[idx];
+  float r = g;
+  if (act == ACT_TANH) r = g * (1.f - yv * yv);
+  else if (act == ACT_RELU) r = yv > 0.f ? g : 0.f;
+  else if (act == ACT_EXP) r = g * yv;
+  o[idx] = r;
+}
+int launch_act_bwd(long n, int act, const float* y, const float* dy, float* o, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, GRID1D(n), 0, s, n, act, y, dy, o);
+  CVAE_LAUNCH_CHECK("act_bwd_kernel");
+  return 0;
+}
+
+__global__ void axpy_kernel(long n, const float* __restrict__ x, float a, float* __restrict__ y) {
+  IDX1D(n);
+  y[idx] += a * x[idx];
+}
+int launch_axpy(long n, const float* x, float a, float* y, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, GRID1D(n), 0, s, n, x, a, y);
+  CVAE_LAUNCH_CHECK("axpy_kernel");
+  return 0;
+}
+
+// out[r] = sum_t x[t*R + r]
+__global__ void sum_time_kernel(int T, int R, const float* __restrict__ x, float* __restrict__ out) {
+  IDX1D(R);
+  float acc = 0.f;
+  for (int t = 0; t < T; ++t) acc += x[(long)t * R + idx];
+  out[idx] = acc;
+}
+int launch_sum_time(const float* x, int T, int R, float* out, hipStream_t s) {
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(sum_time_kernel, GRID1D(R), 0, s, T, R, x, out);
+  CVAE_LAUNCH_CHECK("sum_time_kernel");
+  return 0;
+}
+
+// g_row[t*R + r] = gsent[r]
+__global__ void bcast_time_kernel(int T, int R, const float* __restrict__ g, float* __restrict__ out) {
+  IDX1D((long)T * R);
+  out[idx] = g[idx % R];
+}
+int launch_bcast_time(const float* g, int T, int R, float* out, hipStream_t s) {
+  if ((long)T * R == 0) return 0;
+  hipLaunchKernelGGL(bcast_time_kernel, GRID1D((long)T * R), 0, s, T, R, g, out);
+  CVAE_LAUNCH_CHECK("bcast_time_kernel");
+  return 0;
+}
+
+// dst[r, c0 + c] = src[r, c]   /   dst[r, c] = src[r, c0 + c]
+__global__ void copy_cols_kernel(int R, int C, const float* __restrict__ src, long lds, int soff,
+                                 float* __restrict__ dst, long ldd, int doff) {
+  IDX1D((long)R * C);
+  const int c = (int)(idx % C), r = (int)(idx / C);
+  dst[(long)r * ldd + doff + c] = src[(long)r * lds + soff + c];
+}
+int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* dst, long ldd, int doff,
+                     hipStream_t s) {
+  if ((long)R * C == 0) return 0;
+  hipLaunchKernelGGL(copy_cols_kernel, GRID1D((long)R * C), 0, s, R, C, src, lds, soff, dst, ldd, doff);
+  CVAE_LAUNCH_CHECK("copy_cols_kernel");
+  return 0;
+}
+
+__global__ void targets_tm_kernel(int B, int T, int R, const int64_t* __restrict__ eos, int64_t* __restrict__ out) {
+  IDX1D((long)T * R);
+  const int r = (int)(idx % R), t = (int)(idx / R);
+  out[idx] = eos[(long)(r % B) * T + t];
+}
+int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s) {
+  if ((long)T * R == 0) return 0;
+  hipLaunchKernelGGL(targets_tm_kernel, GRID1D((long)T * R), 0, s, B, T, R, eos, out);
+  CVAE_LAUNCH_CHECK("targets_tm_kernel");
+  return 0;
+}
+
+// logits[b, t, v] = tmp[t*B + b, v]
+__global__ void logits_bt_kernel(int T, int B, long V, const float* __restrict__ tmp, float* __restrict__ out) {
+  IDX1D((long)T * B * V);
+  const long v = idx % V;
+  const int t = (int)((idx / V) % T), b = (int)(idx / (V * T));
+  out[idx] = tmp[((long)t * B + b) * V + v];
+}
+int launch_logits_bt(int T, int B, long V, const float* tmp, float* out, hipStream_t s) {
+  if ((long)T * B * V == 0) return 0;
+  hipLaunchKernelGGL(logits_bt_kernel, GRID1D((long)T * B * V), 0, s, T, B, V, tmp, out);
+  CVAE_LAUNCH_CHECK("logits_bt_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ latent-space kernels
+__global__ void reparam_fwd_kernel(int n, int B, int Z, const float* __restrict__ mu, const float* __restrict__ sigma,
+                                   const float* __restrict__ eps, float* __restrict__ z) {
+  IDX1D((long)n * B * Z);
+  const long bz = idx % ((long)B * Z);
+  z[idx] = mu[bz] + sigma[bz] * eps[idx];
+}
+int launch_reparam_fwd(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
+                       hipStream_t s) {
+  if ((long)n * B * Z == 0) return 0;
+  hipLaunchKernelGGL(reparam_fwd_kernel, GRID1D((long)n * B * Z), 0, s, n, B, Z, mu, sigma, eps, z);
+  CVAE_LAUNCH_CHECK("reparam_fwd_kernel");
+  return 0;
+}
+
+__global__ void reparam_bwd_kernel(long n, const float* __restrict__ dz, const float* __restrict__ eps,
+                                   float* __restrict__ dmu, float* __restrict__ dsigma) {
+  IDX1D(n);
+  dmu[idx] += dz[idx];
+  dsigma[idx] += dz[idx] * eps[idx];
+}
+int launch_reparam_bwd(const float* dz, const float* eps, int B, int Z, float* dmu, float* dsigma, hipStream_t s) {
+  if ((long)B * Z == 0) return 0;
+  hipLaunchKernelGGL(reparam_bwd_kernel, GRID1D((long)B * Z), 0, s, (long)B * Z, dz, eps, dmu, dsigma);
+  CVAE_LAUNCH_CHECK("reparam_bwd_kernel");
+  return 0;
+}
+
+// one wave per sentence; lanes stride over Z
+__global__ __launch_bounds__(256) void kl_fwd_kernel(int B, int Z, const float* __restrict__ mu,
+                                                     const float* __restrict__ sigma, const float* __restrict__ mu_p,
+                                                     const float* __restrict__ sigma_p, float* __restrict__ kl) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int j = lane; j < Z; j += 64) {
+    const float m = mu[(long)b * Z + j], sg = sigma[(long)b * Z + j];
+    if (mu_p) {
+      const float mp = mu_p[(long)b * Z + j], sp = sigma_p[(long)b * Z + j];
+      const float vr = (sg / sp) * (sg / sp), t1 = ((m - mp) / sp) * ((m - mp) / sp);
+      acc += 0.5f * (vr + t1 - 1.f - logf(vr));
+    } else {
+      const float vr = sg * sg;
+      acc += 0.5f * (vr + m * m - 1.f - logf(vr));
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) kl[b] = acc;
+}
+int launch_kl_fwd(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, int B, int Z,
+                  float* kl, hipStream_t s) {
+  if (B == 0) return 0;
+  CVAE_REQUIRE((mu_p == nullptr) == (sigma_p == nullptr), "kl: prior needs both mu_p and sigma_p");
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, B, Z, mu, sigma, mu_p, sigma_p, kl);
+  CVAE_LAUNCH_CHECK("kl_fwd_kernel");
+  return 0;
+}
+
+__global__ void kl_bwd_kernel(int B, int Z, const float* __restrict__ mu, const float* __restrict__ sigma,
+                              const float* __restrict__ mu_p, const float* __restrict__ sigma_p,
+                              const float* __restrict__ gkl, float* __restrict__ dmu, float* __restrict__ dsigma,
+                              float* __restrict__ dmu_p, float* __restrict__ dsigma_p) {
+  IDX1D((long)B * Z);
+  const float g = gkl[idx / Z];
+  const float m = mu[idx], sg = sigma[idx];
+  if (mu_p) {
+    const float mp = mu_p[idx], sp = sigma_p[idx];
+    const float sp2 = sp * sp, d = m - mp;
+    dmu[idx] = g * d / sp2;
+    dsigma[idx] = g * (sg / sp2 - 1.f / sg);
+    if (dmu_p) dmu_p[idx] = -g * d / sp2;
+    if (dsigma_p) dsigma_p[idx] = g * (-(sg * sg) / (sp2 * sp) - d * d / (sp2 * sp) + 1.f / sp);
+  } else {
+    dmu[idx] = g * m;
+    dsigma[idx] = g * (sg - 1.f / sg);
+  }
+}
+int launch_kl_bwd(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, const float* gkl,
+                  int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p, hipStream_t s) {
+  if ((long)B * Z == 0) return 0;
+  hipLaunchKernelGGL(kl_bwd_kernel, GRID1D((long)B * Z), 0, s, B, Z, mu, sigma, mu_p, sigma_p, gkl, dmu, dsigma,
+                     dmu_p, dsigma_p);
+  CVAE_LAUNCH_CHECK("kl_bwd_kernel");
+  return 0;
+}
+
+__constant__ float kImqScales[7] = {.1f, .2f, .5f, 1.f, 2.f, 5.f, 10.f};
+
+__global__ __launch_bounds__(256) void couple_fwd_kernel(int B, int E, int Z, int euclid,
+                                                         const float* __restrict__ a, const float* __restrict__ c,
+                                                         float* __restrict__ d, float* __restrict__ loss) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int j = lane; j < E; j += 64) {
+    const float t = a[(long)b * E + j] - c[(long)b * E + j];
+    acc += t * t;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    d[b] = acc;
+    if (euclid) {
+      loss[b] = acc;
+    } else {
+      float imq = 0.f;
+      for (int k = 0; k < 7; ++k) {
+        const float C = 2.f * Z * kImqScales[k];
+        imq += C / (C + acc);
+      }
+      loss[b] = -imq;
+    }
+  }
+}
+int launch_couple_fwd(const float* a, const float* c, int B, int E, int Z, int euclid, float* d, float* loss,
+                      hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(couple_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, B, E, Z, euclid, a, c, d, loss);
+  CVAE_LAUNCH_CHECK("couple_fwd_kernel");
+  return 0;
+}
+
+__global__ void couple_bwd_kernel(int B, int E, int Z, int euclid, const float* __restrict__ a,
+                                  const float* __restrict__ c, const float* __restrict__ d,
+                                  const float* __restrict__ g, float* __restrict__ da) {
+  IDX1D((long)B * E);
+  const int b = (int)(idx / E);
+  float dl_dd = 1.f;
+  if (!euclid) {
+    dl_dd = 0.f;
+    const float dd = d[b];
+    for (int k = 0; k < 7; ++k) {
+      const float C = 2.f * Z * kImqScales[k];
+      dl_dd += C / ((C + dd) * (C + dd));
+    }
+  }
+  da[idx] = g[b] * dl_dd * 2.f * (a[idx] - c[idx]);
+}
+int launch_couple_bwd(const float* a, const float* c, const float* d, const float* g, int B, int E, int Z,
+                      int euclid, float* da, hipStream_t s) {
+  if ((long)B * E == 0) return 0;
+  hipLaunchKernelGGL(couple_bwd_kernel, GRID1D((long)B * E), 0, s, B, E, Z, euclid, a, c, d, g, da);
+  CVAE_LAUNCH_CHECK("couple_bwd_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ IW estimator (a13/a14)
+// One block per sentence b.  Pass 1: log-weights w_k = log p(z) - xent - log q(z|x) for all K
+// samples (kept in LDS), running sums for kl / xent.  Pass 2: max-shifted log-sum-exp.
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+__global__ __launch_bounds__(256) void iw_reduce_kernel(int K, int B, int Z, const float* __restrict__ z,
+                                                        const float* __restrict__ xent, const float* __restrict__ mu,
+                                                        const float* __restrict__ sigma,
+                                                        const float* __restrict__ mu_p,
+                                                        const float* __restrict__ sigma_p, float* __restrict__ nll,
+                                                        float* __restrict__ kl, float* __restrict__ xent_mean) {
+  extern __shared__ float w[];          // [K] log-weights, then 3*4 floats of block-reduction space
+  float* red = w + K;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float kl_acc = 0.f, x_acc = 0.f, wmax = -INFINITY;
+  for (int k = tid; k < K; k += blockDim.x) {
+    const float* zk = z + ((long)k * B + b) * Z;
+    float lq = 0.f, lp = 0.f;
+    for (int j = 0; j < Z; ++j) {
+      const float zv = zk[j], m = mu[(long)b * Z + j], sg = sigma[(long)b * Z + j];
+      lq += -((zv - m) * (zv - m)) / (2.f * sg * sg) - logf(sg) - kHalfLog2Pi;
+      if (mu_p) {
+        const float mp = mu_p[(long)b * Z + j], sp = sigma_p[(long)b * Z + j];
+        lp += -((zv - mp) * (zv - mp)) / (2.f * sp * sp) - logf(sp) - kHalfLog2Pi;
+      } else {
+        lp += -(zv * zv) * 0.5f - kHalfLog2Pi;
+      }
+    }
+    const float xe = xent[(long)k * B + b];
+    const float wk = lp - xe - lq;
+    w[k] = wk;
+    wmax = fmaxf(wmax, wk);
+    kl_acc += lq - lp;
+    x_acc += xe;
+  }
+  kl_acc = wave_sum(kl_acc); x_acc = wave_sum(x_acc); wmax = wave_max(wmax);
+  if (lane == 0) { red[wave] = kl_acc; red[4 + wave] = x_acc; red[8 + wave] = wmax; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float M = -INFINITY, klt = 0.f, xt = 0.f;
+  for (int i = 0; i < nw; ++i) { klt += red[i]; xt += red[4 + i]; M = fmaxf(M, red[8 + i]); }
+  __syncthreads();
+  float sacc = 0.f;
+  for (int k = tid; k < K; k += blockDim.x) sacc += expf(w[k] - M);
+  sacc = wave_sum(sacc);
+  if (lane == 0) red[wave] = sacc;
+  __syncthreads();
+  if (tid == 0) {
+    float st = 0.f;
+    for (int i = 0; i < nw; ++i) st += red[i];
+    nll[b] = -(M + logf(st) - logf((float)K));
+    kl[b] = klt / K;
+    xent_mean[b] = xt / K;
+  }
+}
+int launch_iw_reduce(const float* z, const float* xent, const float* mu, const float* sigma, const float* mu_p,
+                     const float* sigma_p, int K, int B, int Z, float* nll, float* kl, float* xent_mean,
+                     hipStream_t s) {
+  CVAE_REQUIRE(K > 0 && B >= 0 && Z > 0, "iw_reduce: bad shape");
+  CVAE_REQUIRE(K <= 12000, "iw_reduce: K=%d exceeds the LDS-resident limit (12000)", K);
+  CVAE_REQUIRE((mu_p == nullptr) == (sigma_p == nullptr), "iw_reduce: prior needs both mu_p and sigma_p");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(iw_reduce_kernel, dim3(B), dim3(256), (K + 12) * sizeof(float), s, K, B, Z, z, xent, mu, sigma,
+                     mu_p, sigma_p, nll, kl, xent_mean);
+  CVAE_LAUNCH_CHECK("iw_reduce_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ MI (a15)
+// Block (k, i): sample z[k,i,:].  Threads loop over j: log q(z | x_j); online LSE over j != i.
+// out_lqzx[k,i] = log q(z|x_i), out_lqz[k,i] = LSE_{j!=i} - log(B-1).
+__global__ __launch_bounds__(256) void mi_pair_kernel(int K, int B, int Z, const float* __restrict__ z,
+                                                      const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                      float* __restrict__ lqzx, float* __restrict__ lqz) {
+  extern __shared__ float sh[];         // z row [Z] + reduction space [8]
+  float* zrow = sh;
+  float* red = sh + Z;
+  const int i = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < Z; j += blockDim.x) zrow[j] = z[((long)k * B + i) * Z + j];
+  __syncthreads();
+  float m = -INFINITY, sacc = 0.f;
+  for (int j = tid; j < B; j += blockDim.x) {
+    float lp = 0.f;
+    for (int d = 0; d < Z; ++d) {
+      const float mm = mu[(long)j * Z + d], sg = sigma[(long)j * Z + d], t = zrow[d] - mm;
+      lp += -(t * t) / (2.f * sg * sg) - logf(sg) - kHalfLog2Pi;
+    }
+    if (j == i) { lqzx[(long)k * B + i] = lp; continue; }
+    const float M = fmaxf(m, lp);
+    sacc = sacc * ((m == M) ? 1.f : expf(m - M)) + expf(lp - M);
+    m = M;
+  }
+  // block-wide (m, s) merge
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sacc, o, 64);
+    const float M = fmaxf(m, m2);
+    sacc = sacc * ((m == M) ? 1.f : expf(m - M)) + s2 * ((m2 == M) ? 1.f : expf(m2 - M));
+    m = M;
+  }
+  if (lane == 0) { red[wave] = m; red[4 + wave] = sacc; }
+  __syncthreads();
+  if (tid == 0) {
+    float Mx = -INFINITY, st = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int w2 = 0; w2 < nw; ++w2) Mx = fmaxf(Mx, red[w2]);
+    for (int w2 = 0; w2 < nw; ++w2) st += red[4 + w2] * ((red[w2] == Mx) ? 1.f : expf(red[w2] - Mx));
+    lqz[(long)k * B + i] = Mx + logf(st) - logf((float)(B - 1));
+  }
+}
+
+// mi[i] = mean_k lqzx[k,i] - mean_k lqz[k,i]
+__global__ void mi_mean_kernel(int K, int B, const float* __restrict__ lqzx, const float* __restrict__ lqz,
+                               float* __restrict__ mi) {
+  IDX1D(B);
+  float a = 0.f, c = 0.f;
+  for (int k = 0; k < K; ++k) { a += lqzx[(long)k * B + idx]; c += lqz[(long)k * B + idx]; }
+  mi[idx] = a / K - c / K;
+}
+
+int launch_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* lqzx, float* lqz,
+              float* mi, hipStream_t s) {
+  CVAE_REQUIRE(K > 0 && B > 1 && Z > 0 && K <= 65535, "mi: bad shape K=%d B=%d Z=%d", K, B, Z);
+  hipLaunchKernelGGL(mi_pair_kernel, dim3(B, K), dim3(256), (Z + 8) * sizeof(float), s, K, B, Z, z, mu, sigma, lqzx,
+                     lqz);
+  CVAE_LAUNCH_CHECK("mi_pair_kernel");
+  hipLaunchKernelGGL(mi_mean_kernel, GRID1D(B), 0, s, K, B, lqzx, lqz, mi);
+  CVAE_LAUNCH_CHECK("mi_mean_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ clip + Adam (a12)
+// sumsq[0] = sum over all grads^2, sumsq[1] = sum over the alias segment
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
+                                                    float* __restrict__ out) {
+  float all = 0.f, al = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = g[i];
+    all += v * v;
+    if (i >= a0 && i < a1) al += v * v;
+  }
+  all = wave_sum(all); al = wave_sum(al);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, all);
+    if (al != 0.f) atomicAdd(out + 1, al);
+  }
+}
+
+struct AdamSteps { float step_size[8]; float bc2_sqrt[8]; };   // per listing: lr/(1-b1^t), sqrt(1-b2^t)
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1, int mult, float max_norm,
+                                                        float b1, float b2, float eps, AdamSteps other,
+                                                        AdamSteps alias_steps, const float* __restrict__ sumsq,
+                                                        float* __restrict__ p, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ norm_out) {
+  // total norm as clip_grad_norm_ sees it: the aliased segment is listed `mult` times
+  const float total = sqrtf(sumsq[0] + (float)(mult - 1) * sumsq[1]);
+  float coef = max_norm / (total + 1e-6f);
+  coef = coef > 1.f ? 1.f : coef;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const bool alias = (i >= a0 && i < a1);
+    const int reps = alias ? mult : 1;
+    float gv = g[i];
+    for (int r = 0; r < reps; ++r) gv *= coef;        // scaled once per listing
+    g[i] = gv;
+    float pv = p[i], mv = m[i], vv = v[i];
+    for (int r = 0; r < reps; ++r) {                  // one full Adam step per listing
+      mv = mv + (gv - mv) * (1.f - b1);               // lerp_
+      vv = vv * b2 + gv * gv * (1.f - b2);
+      const float ss = alias ? alias_steps.step_size[r] : other.step_size[0];
+      const float bs = alias ? alias_steps.bc2_sqrt[r] : other.bc2_sqrt[0];
+      const float denom = sqrtf(vv) / bs + eps;
+      pv = pv - ss * (mv / denom);
+    }
+    p[i] = pv; m[i] = mv; v[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+}
+
+int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
+                     float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
+                     float* sumsq, float* norm_out, hipStream_t s) {
+  CVAE_REQUIRE(n >= 0 && alias_off >= 0 && alias_n >= 0 && alias_off + alias_n <= n && mult >= 1 && mult <= 8,
+               "clip_adam: bad segment (alias_mult must be 1..8)");
+  if (n == 0) return 0;
+  CVAE_REQUIRE(p && g && m && v && sumsq, "clip_adam: null operand");
+  CVAE_TRY(check_hip(hipMemsetAsync(sumsq, 0, 2 * sizeof(float), s), "clip_adam memset"));
+  int grid = cdiv(n, 256 * 8);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, g, sumsq);
+  CVAE_LAUNCH_CHECK("sumsq_kernel");
+  AdamSteps so = {}, sa = {};
+  so.step_size[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_other + 1))));
+  so.bc2_sqrt[0] = (float)sqrt(1.0 - pow((double)b2, (double)(step_other + 1)));
+  for (int r = 0; r < mult; ++r) {
+    sa.step_size[r] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_alias + 1 + r))));
+    sa.bc2_sqrt[r] = (float)sqrt(1.0 - pow((double)b2, (double)(step_alias + 1 + r)));
+  }
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, mult,
+                     max_norm, b1, b2, eps, so, sa, sumsq, p, g, m, v, norm_out);
+  CVAE_LAUNCH_CHECK("clip_adam_kernel");
+  return 0;
+}
+
+}  // namespace cvae

@@ -1,0 +1,55 @@
+// Launchers of misc.hip / projce.hip used by api.hip.
+#pragma once
+#include "common.hpp"
+
+namespace cvae {
+
+int launch_pack_batch(const int64_t* flat, const int64_t* off, int B, int max_len, int width, int64_t pad,
+                      int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out, int64_t* len,
+                      hipStream_t s);
+int launch_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, hipStream_t s);
+int launch_embed(int T, int R, int E, int with_cond, int prefix, const int64_t* ids, int Bids, const float* emb,
+                 const float* cond, const float* mask, const int64_t* mask_rows, float* out, hipStream_t s);
+int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* ids, const float* dX,
+                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s);
+int launch_dec_dinit(int T, int B, int E, const float* dX, const float* mask, float* dinit, hipStream_t s);
+int launch_mul(long n, const float* a, const float* b, float* o, hipStream_t s);
+int launch_act_bwd(long n, int act, const float* y, const float* dy, float* o, hipStream_t s);
+int launch_axpy(long n, const float* x, float a, float* y, hipStream_t s);
+int launch_sum_time(const float* x, int T, int R, float* out, hipStream_t s);
+int launch_bcast_time(const float* g, int T, int R, float* out, hipStream_t s);
+int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* dst, long ldd, int doff,
+                     hipStream_t s);
+int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s);
+int launch_logits_bt(int T, int B, long V, const float* tmp, float* out, hipStream_t s);
+int launch_reparam_fwd(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
+                       hipStream_t s);
+int launch_reparam_bwd(const float* dz, const float* eps, int B, int Z, float* dmu, float* dsigma, hipStream_t s);
+int launch_kl_fwd(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, int B, int Z,
+                  float* kl, hipStream_t s);
+int launch_kl_bwd(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, const float* gkl,
+                  int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p, hipStream_t s);
+int launch_couple_fwd(const float* a, const float* c, int B, int E, int Z, int euclid, float* d, float* loss,
+                      hipStream_t s);
+int launch_couple_bwd(const float* a, const float* c, const float* d, const float* g, int B, int E, int Z,
+                      int euclid, float* da, hipStream_t s);
+int launch_iw_reduce(const float* z, const float* xent, const float* mu, const float* sigma, const float* mu_p,
+                     const float* sigma_p, int K, int B, int Z, float* nll, float* kl, float* xent_mean,
+                     hipStream_t s);
+int launch_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* lqzx, float* lqz,
+              float* mi, hipStream_t s);
+int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
+                     float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
+                     float* sumsq, float* norm_out, hipStream_t s);
+
+// projce.hip
+long projce_workspace_floats(int N, int V);
+int launch_projce_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                          int N, int E, int V, float* loss, float* lse, float* ws, hipStream_t s);
+long projce_bwd_workspace_floats(int N, int V);
+int launch_projce_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                           const float* lse, const float* gloss, int N, int E, int V, float* dX, float* dW,
+                           float* db, float* ws, hipStream_t s);
+int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStream_t s);
+
+}  // namespace cvae

@@ -73,9 +73,11 @@ int launch_rnn_forward(const RnnFwd& a, hipStream_t s) {
   const bool small = a.R <= SKINNY_MAX_ROWS;
   CVAE_REQUIRE(small || a.hp_scratch, "rnn_forward: hp_scratch required for R > %d", SKINNY_MAX_ROWS);
   const int init_slot = a.reverse ? a.T : 0;
-  if (a.h0) CVAE_TRY(check_hip(hipMemcpyAsync(a.hs + init_slot * RH, a.h0, RH * 4, hipMemcpyDeviceToDevice, s), "h0 copy"));
+  if (a.init_in_place) {
+    // nothing to do
+  } else if (a.h0) CVAE_TRY(check_hip(hipMemcpyAsync(a.hs + init_slot * RH, a.h0, RH * 4, hipMemcpyDeviceToDevice, s), "h0 copy"));
   else CVAE_TRY(check_hip(hipMemsetAsync(a.hs + init_slot * RH, 0, RH * 4, s), "h0 memset"));
-  if (a.cell == CELL_LSTM) {
+  if (a.cell == CELL_LSTM && !a.init_in_place) {
     if (a.c0) CVAE_TRY(check_hip(hipMemcpyAsync(a.cs + init_slot * RH, a.c0, RH * 4, hipMemcpyDeviceToDevice, s), "c0 copy"));
     else CVAE_TRY(check_hip(hipMemsetAsync(a.cs + init_slot * RH, 0, RH * 4, s), "c0 memset"));
   }

@@ -1,0 +1,107 @@
+"""ctypes binding of libcvae_hip.so (include/cvae_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at
+import, and every call checks the library's return code.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcvae_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'libcvae_hip.so not found at %s: build it with `make -C coupled-vae_amd/csrc` '
+        '(or `python -c "import __graft_entry__ as g; g.build()"`). There is no CPU fallback.' % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes, exactly as declared in include/cvae_hip.h (restype int unless listed)
+SIGNATURES = {
+    'cvae_version': [],
+    'cvae_init': [I],
+    'cvae_pack_batch': [P, P, I, I, I, L, L, L, P, P, P, P, P],
+    'cvae_sort_resort': [P, I, P, P, P],
+    'cvae_gemm': [I, I, I, I, I, P, L, P, L, P, L, P, I, I, P],
+    'cvae_linear_forward': [P, P, P, I, I, I, I, P, P],
+    'cvae_linear_backward': [P, P, P, P, I, I, I, I, P, P, P, P, P],
+    'cvae_encoder_forward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cvae_encoder_backward_scratch': [I, I, I, I, I],
+    'cvae_encoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cvae_decoder_forward': [I, I, I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cvae_decoder_backward_scratch': [I, I, I, I, I],
+    'cvae_decoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cvae_projce_workspace': [L, L],
+    'cvae_projce_forward': [P, P, P, P, L, I, I, I, L, P, P, P, P, P],
+    'cvae_projce_backward_workspace': [L, L],
+    'cvae_projce_backward': [P, P, P, P, L, P, P, I, I, I, L, P, P, P, P, P],
+    'cvae_targets_time_major': [P, I, I, I, P, P],
+    'cvae_logits': [P, P, P, I, I, I, L, P, P, P],
+    'cvae_reparam_forward': [P, P, P, I, I, I, P, P],
+    'cvae_reparam_backward': [P, P, I, I, P, P, P],
+    'cvae_kl_forward': [P, P, P, P, I, I, P, P],
+    'cvae_kl_backward': [P, P, P, P, P, I, I, P, P, P, P, P],
+    'cvae_couple_forward': [P, P, I, I, I, I, P, P, P],
+    'cvae_couple_backward': [P, P, P, P, I, I, I, I, P, P],
+    'cvae_iw_reduce': [P, P, P, P, P, P, I, I, I, P, P, P, P],
+    'cvae_mi': [P, P, P, I, I, I, P, P, P],
+    'cvae_clip_adam': [P, P, P, P, L, L, L, I, F, F, F, F, F, L, L, P, P, P],
+    'cvae_sum_time': [P, I, I, P, P],
+    'cvae_axpy': [P, F, L, P, P],
+}
+_RESTYPE_LONG = {'cvae_encoder_backward_scratch', 'cvae_decoder_backward_scratch', 'cvae_projce_workspace',
+                 'cvae_projce_backward_workspace'}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
+    _fn.argtypes = _args
+    _fn.restype = L if _name in _RESTYPE_LONG else I
+lib.cvae_last_error.argtypes = []
+lib.cvae_last_error.restype = ctypes.c_char_p
+
+
+class CvaeHipError(RuntimeError):
+    pass
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'libcvae_hip needs contiguous tensors'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CvaeHipError('%s failed (%d): %s' % (name, rc, lib.cvae_last_error().decode()))
+
+
+def query(name, *args):
+    return int(getattr(lib, name)(*args))
+
+
+def ptr_array(tensors):
+    """const float* const* argument: a host array of device pointers (kept alive by the caller)."""
+    arr = (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return arr
+
+
+_initialised = set()
+
+
+def init(device_index=None):
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _initialised:
+        call('cvae_init', device_index)
+        _initialised.add(device_index)

@@ -1,0 +1,56 @@
+"""Synthetic corpora and on-device batch layout (a1).
+
+The reference's file readers and pickled vocabularies are out of scope; what is kept
+bit-exact is the tensor layout `process_raw_sent` produces (CV/dataloaders/ptb.py:118-129),
+built on the GPU by cvae_pack_batch from CSR token ids."""
+import numpy as np
+import torch
+
+from . import ops
+
+PAD, GO, EOS, UNK = 0, 1, 2, 3     # CV/utils/vocab.py:29-30
+
+SHAPES = {
+    # name: V, E, H, Z, lognormal mu, sigma, cap   
+    'ptb': dict(V=10002, E=200, H=128, Z=32, mu=3.0, sigma=0.45, cap=82),
+    'yelp': dict(V=20000, E=200, H=256, Z=32, mu=4.4, sigma=0.5, cap=200),
+    'yahoo': dict(V=20001, E=200, H=256, Z=32, mu=4.2, sigma=0.5, cap=200),
+    'switchboard': dict(V=10000, E=200, H=128, Z=32, mu=2.6, sigma=0.6, cap=200),
+    'scaleup': dict(V=50000, E=200, H=1024, Z=32, mu=4.4, sigma=0.5, cap=200),
+}
+
+
+def synthetic_sentences(n, V, mu, sigma, cap, seed=0):
+    """ids uniform in [4,V), len = clip(floor(lognormal(mu,sigma)), 1, cap)."""
+    rs = np.random.RandomState(seed)
+    lens = np.clip(np.floor(rs.lognormal(mu, sigma, size=n)), 1, cap).astype(np.int64)
+    return [rs.randint(4, V, size=int(l)).astype(np.int64) for l in lens]
+
+
+class Corpus(object):
+    """Token ids in CSR form on the host; batches are laid out on the device."""
+
+    def __init__(self, sentences, max_len=200):
+        self.sentences = [np.asarray(s, dtype=np.int64) for s in sentences]
+        self.max_len = max_len
+        self.lengths = np.asarray([min(len(s), max_len) for s in self.sentences], dtype=np.int64)
+
+    def __len__(self):
+        return len(self.sentences)
+
+    def batch(self, idx, device, truncate=True):
+        """-> bare (B,L), go (B,L+1), eos (B,L+1), len (B,) int64 on `device`.
+        truncate=True: training layout (cut to the batch maximum, Experiment.py:659-664)."""
+        sents = [self.sentences[i] for i in idx]
+        flat = np.concatenate(sents) if sents else np.zeros((0,), np.int64)
+        off = np.cumsum([0] + [len(s) for s in sents]).astype(np.int64)
+        width = int(self.lengths[list(idx)].max()) if truncate else self.max_len
+        flat_d = torch.from_numpy(flat).to(device, non_blocking=True)
+        off_d = torch.from_numpy(off).to(device, non_blocking=True)
+        if flat_d.numel() == 0:
+            flat_d = torch.zeros((1,), dtype=torch.int64, device=device)
+        return ops.pack_batch(flat_d, off_d, self.max_len, width, PAD, GO, EOS)
+
+    def n_tokens(self, idx):
+        """PPL denominator: len + 1 per sentence (Experiment.py:1394)."""
+        return int((self.lengths[list(idx)] + 1).sum())

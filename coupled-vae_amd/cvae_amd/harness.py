@@ -1,0 +1,227 @@
+"""Harness: the semantics of the reference's Experiment.train_epoch / language_modeling /
+estimate_mi / evaluate_dialogue for the hot path (loss assembly, lambda_KL schedule,
+clip + Adam with the duplicate-embedding behaviour, corpus reductions), plus what the
+reference does not have: data-parallel training and sharded evaluation over RCCL.
+
+Reference: CV/Experiment.py:509-558,578-621,639-775,1323-1396,1453-1503;
+           CC/Experiment.py:311-428,538-621.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .modules import MODEL_CLASSES
+from .settings import settings
+
+
+class HParams(object):
+    """The values config.Config carries for the hot path (CV/config.py:40-84, CC/config.py:22-66)."""
+
+    def __init__(self, model='vae-couple', cell='gru', V=10002, E=200, H=128, Z=32, dropout=0.2, lr=1e-3,
+                 beta1=0.9, beta2=0.999, clip_norm=30.0, kl_annealing=True, annealing_start=2000,
+                 annealing_step=40000, lambda_couple=0.1, lambda_seq_couple=1.0, euclidean_dist=False,
+                 max_len=200, batch_size=32, pad_id=0):
+        self.__dict__.update(locals())
+        del self.__dict__['self']
+
+    def is_couple(self):
+        return self.model.endswith('couple')
+
+    def is_dialog(self):
+        return self.model.startswith('cvae')
+
+
+def lambda_kl(iter_num, hp):
+    """CV/Experiment.py:556."""
+    if not hp.kl_annealing:
+        return 1.0
+    return float(min(max(np.round((iter_num - hp.annealing_start) / hp.annealing_step, decimals=6), 0), 1))
+
+
+def build_model(hp, device, seed=None):
+    """Same construction order as Experiment.__init__ (CV/Experiment.py:93-146): one shared
+    nn.Embedding initialised N(0,1) (utils/vocab.py:22-23), then the model."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    settings.use_lstm = (hp.cell == 'lstm')
+    emb = nn.Embedding.from_pretrained(torch.zeros(hp.V, hp.E).normal_(0, 1), freeze=False)
+    cls = MODEL_CLASSES[hp.model]
+    model = cls(hid_dim=hp.H, latent_dim=hp.Z, enc_layers=1, dec_layers=1, dropout=hp.dropout, enc_bi=True,
+                dec_max_len=hp.max_len, beam_size=1, WEAtt_type='none', encoder_emb=emb, decoder_emb=emb,
+                pad_id=hp.pad_id)
+    return model.to(device)
+
+
+class FlatAdam(object):
+    """All unique parameters live in one fp32 arena (and their gradients in another), so that
+    clip_grad_norm_ + Adam is two kernels (cvae_clip_adam).  Reproduces Experiment.step's
+    duplicate listing of the shared embedding: the alias count is the number
+    of state_dict keys naming it."""
+
+    def __init__(self, model, hp):
+        self.hp = hp
+        sd = model.state_dict(keep_vars=True)
+        uniq, self.n_alias, emb = [], 0, None
+        for k, v in sd.items():
+            if not v.requires_grad:
+                continue
+            if k.endswith('Embedding.weight'):
+                self.n_alias += 1
+                emb = v
+            if not any(v is u for u in uniq):
+                uniq.append(v)
+        # embedding first: the alias segment is [0, V*E)
+        uniq.sort(key=lambda t: 0 if t is emb else 1)
+        n = sum(p.numel() for p in uniq)
+        dev = uniq[0].device
+        self.params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.alias_n = emb.numel() if emb is not None else 0
+        off = 0
+        self.views = []
+        for p in uniq:
+            k = p.numel()
+            self.params[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.params[off:off + k].view_as(p.data)
+            p.grad = self.grads[off:off + k].view_as(p.data)
+            self.views.append(p)
+            off += k
+        self.sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.steps = 0
+        self.lr = hp.lr
+
+    def zero_grad(self):
+        self.grads.zero_()
+        for p in self.views:          # keep .grad pointing into the arena
+            if p.grad is None or p.grad.data_ptr() < self.grads.data_ptr():
+                raise RuntimeError('gradient view lost')
+
+    def step(self):
+        mult = max(self.n_alias, 1)
+        ops.clip_adam(self.params, self.grads, self.m, self.v, 0, self.alias_n, mult, self.hp.clip_norm, self.lr,
+                      (self.hp.beta1, self.hp.beta2), 1e-8, self.steps, self.steps * mult, self.sumsq, self.norm)
+        self.steps += 1
+
+
+class Trainer(object):
+    def __init__(self, hp, device, seed=0, model=None):
+        self.hp, self.device = hp, device
+        self.model = model if model is not None else build_model(hp, device, seed)
+        self.model.train(True)
+        self.opt = FlatAdam(self.model, hp)
+        self.iter_num = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    # ---- one training iteration: CV/Experiment.py:646-775 / CC/Experiment.py:318-428
+    def losses(self, batch):
+        hp, m = self.hp, self.model
+        if hp.is_dialog():
+            out = m(post_bare=batch['post_bare'], post_len=batch['post_len'], resp_go=batch['resp_go'],
+                    resp_len=batch['resp_len'], resp_bare=batch['resp_bare'])
+            eos = batch['resp_eos']
+            if hp.is_couple():
+                logits, prior, post, logits_c, init, init_c = out
+            else:
+                logits, prior, post = out
+            kl = ops.kl_div(post.loc, post.scale, prior.loc, prior.scale)
+        else:
+            out = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
+            eos = batch['eos']
+            if hp.is_couple():
+                logits, post, _, _, logits_c, init, init_c = out
+            else:
+                logits, post, _, _ = out
+            kl = ops.kl_div(post.loc, post.scale)
+        res = {'seq': m.criterionSeq(logits, eos, keep_batch=True).mean(0), 'kl': kl.mean(0)}
+        lam = lambda_kl(self.iter_num, hp)
+        tot = res['seq'] + lam * res['kl']
+        if hp.is_couple():
+            res['seq_c'] = m.criterionSeq(logits_c, eos, keep_batch=True).mean(0)
+            res['couple'] = ops.couple_loss(init, init_c, hp.Z, hp.euclidean_dist).mean(0)
+            tot = tot + res['seq_c'] * hp.lambda_seq_couple + hp.lambda_couple * res['couple']
+        res['tot'] = tot
+        res['lambda_kl'] = lam
+        return res
+
+    def forward_backward(self, batch):
+        self.iter_num += 1
+        self.model.train(True)
+        self.opt.zero_grad()
+        res = self.losses(batch)
+        res['tot'].backward()
+        if self.world > 1:
+            # the batch mean over equal per-rank batches = mean of per-rank gradients; must
+            # complete before the clip (Experiment.py:515 clips the full-batch gradient)
+            dist.all_reduce(self.opt.grads, op=dist.ReduceOp.SUM)
+            self.opt.grads.mul_(1.0 / self.world)
+        return res
+
+    def train_step(self, batch):
+        """forward + backward (+ gradient all-reduce) + clip + Adam.  Returns the loss dict
+        (device scalars: nothing syncs here; read them back in one copy when logging)."""
+        res = self.forward_backward(batch)
+        self.opt.step()
+        return res
+
+    # ---- evaluation: CV/Experiment.py:1323-1396 ; CC/Experiment.py:538-621
+    def iw_eval(self, batches, n_sample):
+        """batches: iterable of batch dicts (this rank's shard).  Returns corpus metrics
+        (nll, xent, kl, ppl), identical on every rank."""
+        self.model.train(False)
+        hp = self.hp
+        acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # sum nll, xent, kl, len+1, count
+        per_sentence = []
+        for b in batches:
+            if hp.is_dialog():
+                xent, nll, kl = self.model.test_lm(post_bare=b['post_bare'], post_len=b['post_len'],
+                                                   resp_go=b['resp_go'], resp_len=b['resp_len'],
+                                                   resp_bare=b['resp_bare'], resp_eos=b['resp_eos'],
+                                                   n_sample=n_sample)
+                ln = b['resp_len']
+            else:
+                xent, nll, kl, _ = self.model.test_lm(bare=b['bare'], sent_len=b['len'], go=b['go'], eos=b['eos'],
+                                                      n_sample=n_sample)
+                ln = b['len']
+            acc += torch.stack([nll.sum().double(), xent.sum().double(), kl.sum().double(),
+                                (ln + 1).sum().double(), torch.tensor(float(nll.numel()), device=self.device).double()])
+            per_sentence.append((xent, nll, kl))
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        a = acc.tolist()
+        self.model.train(True)
+        return dict(nll=a[0] / a[4], xent=a[1] / a[4], kl=a[2] / a[4], ppl=math.exp(a[0] / a[3]),
+                    n=int(a[4])), per_sentence
+
+    def estimate_mi(self, batches, n_sample=100):
+        """CV/Experiment.py:1453-1503: whole batches (the estimator depends on batch
+        composition) are sharded over ranks; final reduction of (sum mi, count)."""
+        self.model.train(False)
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        for b in batches:
+            mi, _ = self.model.estimate_mi(go=b['go'], sent_len=b['len'], bare=b['bare'], n_sample=n_sample)
+            acc += torch.stack([mi.sum().double(), torch.tensor(float(mi.numel()), device=self.device).double()])
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        self.model.train(True)
+        a = acc.tolist()
+        return a[0] / max(a[1], 1.0)
+
+
+def text_batch(corpus, idx, device, truncate=True):
+    bare, go, eos, ln = corpus.batch(idx, device, truncate)
+    return dict(bare=bare, go=go, eos=eos, len=ln)
+
+
+def dialog_batch(posts, resps, idx, device):
+    """CC/Experiment.py:331-339 layout (both sides truncated to their batch maxima)."""
+    pb, _, _, pl = posts.batch(idx, device, True)
+    rb, rg, re_, rl = resps.batch(idx, device, True)
+    return dict(post_bare=pb, post_len=pl, resp_bare=rb, resp_go=rg, resp_eos=re_, resp_len=rl)

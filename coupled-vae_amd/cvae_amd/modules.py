@@ -1,0 +1,456 @@
+"""Host-side mirror of the reference's `Modules` package for the hot path.
+
+Same class names, constructor signatures, method signatures, return tuples and state_dict
+keys as CV/Modules/{encoder,decoder,vae,vae_couple}.py, CC/Modules/{vae,vae_couple}.py and
+CV/Modules/Losses/SeqLoss.py, so that the reference's Experiment.py can drive them
+(INTEGRATION.md).  nn.GRU / nn.LSTM / nn.Linear / nn.Embedding objects are used ONLY as
+parameter containers (identical names, shapes and initialisation order => identical
+state_dict and, for equal seeds, identical initial weights); their forward() is never called.
+All arithmetic goes through libcvae_hip (ops.py).
+
+Out of scope: greedy / beam decoding branches.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .settings import settings
+
+
+# --------------------------------------------------------------------------- noise plumbing
+class NoiseSource(object):
+    """Where dropout masks and Gaussian noise come from.  The default draws them with torch's
+    device generator in exactly the order and shapes the reference does (SURVEY 8a 'RNG draw
+    order'); tests replace it with a replay of recorded tensors."""
+
+    def dropout_mask(self, shape, p, device, name):
+        if p == 0.0:
+            return None
+        return torch.bernoulli(torch.full(shape, 1.0 - p, dtype=torch.float32, device=device)) / (1.0 - p)
+
+    def normal(self, shape, device, name):
+        return torch.empty(shape, dtype=torch.float32, device=device).normal_()
+
+
+class ReplayNoise(NoiseSource):
+    """Replays named tensors (golden fixtures): dict name -> tensor or list of tensors."""
+
+    def __init__(self, table):
+        self.table = {k: (list(v) if isinstance(v, (list, tuple)) else [v]) for k, v in table.items()}
+
+    def _pop(self, name, shape, device):
+        if name not in self.table or not self.table[name]:
+            return None
+        t = self.table[name].pop(0).to(device=device, dtype=torch.float32).contiguous()
+        assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
+        return t
+
+    def dropout_mask(self, shape, p, device, name):
+        return self._pop(name, shape, device)
+
+    def normal(self, shape, device, name):
+        t = self._pop(name, shape, device)
+        if t is None:   # draws whose value is discarded by the model (e.g. eps_couple)
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        return t
+
+
+_noise = NoiseSource()
+
+
+def set_noise_source(src):
+    global _noise
+    _noise = src if src is not None else NoiseSource()
+
+
+def _cell():
+    return ops.LSTM if settings.use_lstm else ops.GRU
+
+
+def _rnn_weights(rnn, reverse=False):
+    suf = '_reverse' if reverse else ''
+    return [getattr(rnn, n + suf) for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+
+
+class LazyLogits(object):
+    """What Decoder.forward returns in place of the (R,T,V) logits tensor: the decoder's
+    `final` states plus the ToVocab parameters.  SeqLoss consumes it through the fused
+    projection + cross-entropy kernel; `.materialize()` builds the real tensor on demand."""
+
+    def __init__(self, final, weight, bias, n_sent):
+        self.final, self.weight, self.bias, self.n_sent = final, weight, bias, n_sent
+
+    @property
+    def shape(self):
+        T, R, _ = self.final.shape
+        return torch.Size([R, T, self.weight.shape[0]])
+
+    def materialize(self):
+        return ops.logits_bt(self.final.detach(), self.weight.detach(), self.bias.detach())
+
+
+# --------------------------------------------------------------------------- SeqLoss
+class SeqLoss(nn.Module):
+    """CV/Modules/Losses/SeqLoss.py.  forward(logits, gts, keep_batch) with logits a LazyLogits."""
+
+    def __init__(self, voc_size, pad, end, unk):
+        super(SeqLoss, self).__init__()
+        self.voc_size = voc_size
+        self.pad = pad
+
+    def forward(self, logits, gts, keep_batch=False):
+        if not isinstance(logits, LazyLogits):
+            raise NotImplementedError('SeqLoss takes the LazyLogits returned by Decoder.forward; dense logits '
+                                      '(BoW loss, lambda_BoW > 0) are outside the accelerated path')
+        if logits.shape[0] == 0:
+            return torch.zeros((), device=gts.device)
+        assert logits.shape[:-1] == gts.shape or logits.shape[0] % gts.shape[0] == 0
+        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, gts[:logits.n_sent], self.pad)
+        if keep_batch:
+            return sent
+        return sent.sum() / (gts != self.pad).sum().to(sent.dtype)
+
+
+# --------------------------------------------------------------------------- Encoder
+class Encoder(nn.Module):
+    """CV/Modules/encoder.py.  Returns (None, last_states (n_dir, B, H)): no caller on the hot
+    path reads the per-step outputs, so they are not produced."""
+
+    def __init__(self, emb_dim, hid_dim, n_layer, dropout, bi, embedding):
+        super(Encoder, self).__init__()
+        assert n_layer == 1 and bi, 'the accelerated path covers the 1-layer bidirectional encoder of every config'
+        self.emb_dim, self.hid_dim, self.n_layer, self.dropout, self.bi = emb_dim, hid_dim, n_layer, dropout, bi
+        self.n_dir = 2
+        self.drop = nn.Dropout(self.dropout)
+        self.Embedding = embedding
+        self.use_lstm = settings.use_lstm
+        kw = dict(input_size=emb_dim, hidden_size=hid_dim, num_layers=n_layer, bidirectional=True)
+        if self.use_lstm:
+            self.LSTM = nn.LSTM(**kw)
+        else:
+            self.GRU = nn.GRU(**kw)
+
+    def last_flat(self, bare, length, noise_name='enc_drop'):
+        """(B, 2H) = [h_fwd | h_bwd]."""
+        rnn = self.LSTM if self.use_lstm else self.GRU
+        w = _rnn_weights(rnn) + _rnn_weights(rnn, True)
+        B, L = bare.shape
+        mask = mask_rows = None
+        if self.training:
+            # the reference draws the mask after sorting by length (encoder.py:50-56)
+            mask = _noise.dropout_mask((L, B, self.emb_dim), self.dropout, bare.device, noise_name)
+            if mask is not None:
+                _, mask_rows = ops.sort_resort(length)
+        cell = ops.LSTM if self.use_lstm else ops.GRU
+        return ops.encoder(cell, bare, length, mask, mask_rows, self.Embedding.weight, w)
+
+    def forward(self, bare, length):
+        last = self.last_flat(bare, length)
+        B = bare.shape[0]
+        return None, last.view(B, 2, self.hid_dim).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------- Decoder
+class Decoder(nn.Module):
+    """Teacher-forcing branch of CV/Modules/vae_couple.py:40-121 (with_init=False) and of
+    CV/Modules/decoder.py:28-113 / CC/Modules/decoder.py (with_init=True: owns toInit)."""
+
+    def __init__(self, voc_size, latent_dim, emb_dim, hid_dim, n_layer, dropout, max_len, beam_size, WEAtt_type,
+                 embedding, with_init=False):
+        super(Decoder, self).__init__()
+        assert n_layer == 1 and WEAtt_type == 'none', 'every shipped config uses 1 layer and WEAtt_type="none"'
+        self.voc_size, self.latent_dim, self.emb_dim, self.hid_dim = voc_size, latent_dim, emb_dim, hid_dim
+        self.n_layers, self.dropout, self.max_len, self.beam_size = n_layer, dropout, max_len, beam_size
+        self.WEAtt_type = WEAtt_type
+        self.drop = nn.Dropout(dropout)
+        self.Embedding = embedding
+        if with_init:
+            self.toInit = nn.Sequential(nn.Linear(latent_dim, emb_dim), nn.ReLU(), nn.Linear(emb_dim, emb_dim))
+        self.use_lstm = settings.use_lstm
+        kw = dict(input_size=emb_dim * 2, hidden_size=hid_dim, num_layers=n_layer, bidirectional=False)
+        if self.use_lstm:
+            self.LSTM = nn.LSTM(**kw)
+        else:
+            self.GRU = nn.GRU(**kw)
+        self.W_c = nn.Linear(hid_dim, emb_dim)
+        self.ToVocab = nn.Linear(emb_dim, voc_size)
+
+    def final_states(self, init_input, helper, train, noise_prefix='dec'):
+        rnn = self.LSTM if self.use_lstm else self.GRU
+        w = _rnn_weights(rnn) + [self.W_c.weight, self.W_c.bias]
+        R = init_input.shape[0]
+        B, T = helper.shape
+        mask_in = mask_out = None
+        if train:
+            dev = helper.device
+            mask_in = _noise.dropout_mask((T, R, 2 * self.emb_dim), self.dropout, dev, noise_prefix + '_in_drop')
+            mask_out = _noise.dropout_mask((T, R, self.hid_dim), self.dropout, dev, noise_prefix + '_out_drop')
+        cell = ops.LSTM if self.use_lstm else ops.GRU
+        return ops.decoder(cell, train, init_input, helper, mask_in, mask_out, self.Embedding.weight, w)
+
+    def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None):
+        if not (self.training or test_lm):
+            raise NotImplementedError('greedy / beam decoding is outside the accelerated hot path (SURVEY 8f.3)')
+        n_sent = helper.shape[0] if _n_sent is None else _n_sent
+        final = self.final_states(init_input, helper[:n_sent], self.training and not test_lm, _noise_prefix)
+        return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, n_sent)
+
+
+def to_init(seq, x):
+    """Linear-ReLU-Linear (vae_couple.py:429-434)."""
+    h = ops.linear(x, seq[0].weight, seq[0].bias, ops.ACT_RELU)
+    return ops.linear(h, seq[2].weight, seq[2].bias, ops.ACT_NONE)
+
+
+# --------------------------------------------------------------------------- Gaussian
+class Gaussian(nn.Module):
+    """CV/Modules/vae_couple.py:781-803."""
+
+    def __init__(self, in_dim, out_dim):
+        super(Gaussian, self).__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.toMiu = nn.Sequential(nn.Linear(in_dim, out_dim))
+        self.toSigma = nn.Sequential(nn.Linear(in_dim, out_dim))
+
+    def params(self, x, need_sigma=True):
+        mu = ops.linear(x, self.toMiu[0].weight, self.toMiu[0].bias, ops.ACT_NONE)
+        sigma = ops.linear(x, self.toSigma[0].weight, self.toSigma[0].bias, ops.ACT_EXP) if need_sigma else None
+        return mu, sigma
+
+    def forward(self, input, _noise_name='eps', _sample=True):
+        mu, sigma = self.params(input)
+        dist = torch.distributions.Normal(mu, sigma, validate_args=False)
+        eps = _noise.normal((1,) + tuple(mu.shape), mu.device, _noise_name).squeeze(0)   # always drawn
+        z = ops.ReparamFn.apply(mu, sigma, eps) if _sample else None
+        return dist, z
+
+
+# --------------------------------------------------------------------------- IW-NLL core
+def _iw_nll(decoder, to_init_seq, go, eos, mu, sigma, mu_p, sigma_p, post_repr, n_sample, pad):
+    """importance_sampling (CV/Modules/vae_couple.py:526-578; CC/...:312-364) on the GPU.
+    eps is drawn in the reference's (2,B,Z) chunks; samples are then decoded `kc` at a time
+    (rows kc*B), which changes nothing numerically per row."""
+    n_chunk = settings.n_sample_chunk
+    assert n_sample % n_chunk == 0
+    B, T = go.shape
+    Z = mu.shape[1]
+    dev = go.device
+    eps = torch.cat([_noise.normal((n_chunk, B, Z), dev, 'iw_eps') for _ in range(n_sample // n_chunk)], 0)
+    z = ops.rsample_n(mu, sigma, eps)                                   # (K,B,Z)
+    kc = max(1, min(n_sample, settings.iw_max_rows // B))
+    xent = torch.empty((n_sample, B), dtype=torch.float32, device=dev)
+    for k0 in range(0, n_sample, kc):
+        k1 = min(n_sample, k0 + kc)
+        zz = z[k0:k1].reshape(-1, Z)
+        init = to_init(to_init_seq, zz)
+        if post_repr is not None:
+            init = init + post_repr.repeat(k1 - k0, 1)
+        final = decoder.final_states(init, go, False)
+        xent[k0:k1] = ops.proj_ce(final, decoder.ToVocab.weight, decoder.ToVocab.bias, eos, pad).view(k1 - k0, B)
+    xm, nll, kl = ops.iw_reduce(z, xent, mu, sigma, mu_p, sigma_p)
+    return xm, nll, kl, z.transpose(0, 1)
+
+
+def _truncate_eval(go, eos, bare, sent_len):
+    """Pad targets carry weight 0 (SeqLoss.py:15-16), so cutting T to max(len)+1 is exact."""
+    if not settings.truncate_eval:
+        return go, eos, bare
+    m = int(sent_len.max())
+    return go[:, :m + 1].contiguous(), eos[:, :m + 1].contiguous(), bare[:, :max(m, 1)].contiguous()
+
+
+# --------------------------------------------------------------------------- text models
+class _TextBase(nn.Module):
+    def _common(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                WEAtt_type, encoder_emb, decoder_emb):
+        assert encoder_emb.num_embeddings == decoder_emb.num_embeddings
+        assert encoder_emb.embedding_dim == decoder_emb.embedding_dim
+        self.voc_size, self.emb_dim = encoder_emb.num_embeddings, encoder_emb.embedding_dim
+        self.hid_dim, self.enc_layers, self.dec_layers, self.dropout = hid_dim, enc_layers, dec_layers, dropout
+        self.enc_bi, self.n_dir = enc_bi, 2 if enc_bi else 1
+        self.dec_max_len, self.beam_size, self.WEAtt_type, self.latent_dim = dec_max_len, beam_size, WEAtt_type, latent_dim
+
+    def _dec_kwargs(self, decoder_emb):
+        return dict(voc_size=self.voc_size, latent_dim=self.latent_dim, emb_dim=self.emb_dim,
+                    hid_dim=self.hid_dim * self.n_dir, n_layer=self.dec_layers, dropout=self.dropout,
+                    max_len=self.dec_max_len, beam_size=self.beam_size, WEAtt_type=self.WEAtt_type,
+                    embedding=decoder_emb)
+
+    def _to_init_seq(self):
+        return self.toInit if hasattr(self, 'toInit') else self.Decoder.toInit
+
+    def estimate_mi(self, go, sent_len, bare, n_sample):
+        """CV/Modules/vae_couple.py:453-502 -> (mi (B,), z (B,K,Z))."""
+        with torch.no_grad():
+            last = self.Encoder.last_flat(bare, sent_len)
+            mu, sigma = self.PosteriorGaussian.params(last)
+            _noise.normal((1,) + tuple(mu.shape), mu.device, 'eps')        # Gaussian.forward always draws
+            n_chunk = settings.n_sample_chunk
+            assert n_sample % n_chunk == 0
+            B, Z = mu.shape
+            eps = torch.cat([_noise.normal((n_chunk, B, Z), mu.device, 'mi_eps')
+                             for _ in range(n_sample // n_chunk)], 0)
+            z = ops.rsample_n(mu, sigma, eps)
+            return ops.mi(z, mu, sigma), z.transpose(0, 1)
+
+    def test_lm(self, go, sent_len, bare, eos, n_sample):
+        """CV/Modules/vae_couple.py:504-524 -> (xent, nll, kl (B,), z (B,K,Z))."""
+        with torch.no_grad():
+            go, eos, bare = _truncate_eval(go, eos, bare, sent_len)
+            last = self.Encoder.last_flat(bare, sent_len)
+            mu, sigma = self.PosteriorGaussian.params(last)
+            _noise.normal((1,) + tuple(mu.shape), mu.device, 'eps')
+            return _iw_nll(self.Decoder, self._to_init_seq(), go, eos, mu, sigma, None, None, None, n_sample,
+                           self.criterionSeq.pad)
+
+
+class VAE(_TextBase):
+    """CV/Modules/vae.py:17-346."""
+
+    def __init__(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                 WEAtt_type, encoder_emb, decoder_emb, pad_id):
+        super(VAE, self).__init__()
+        self._common(hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                     WEAtt_type, encoder_emb, decoder_emb)
+        self.Encoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        self.PosteriorGaussian = Gaussian(hid_dim * self.n_dir * enc_layers, latent_dim)
+        self.Decoder = Decoder(with_init=True, **self._dec_kwargs(decoder_emb))
+        self.BoW = nn.Linear(latent_dim, self.voc_size)
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+
+    def forward(self, go, sent_len=None, bare=None):
+        if not self.training:
+            raise NotImplementedError()
+        last = self.Encoder.last_flat(bare, sent_len)
+        dist, z = self.PosteriorGaussian(last)
+        init = to_init(self.Decoder.toInit, z)
+        logits = self.Decoder(None, init, go)
+        return logits, dist, z, None
+
+
+class VAE_COUPLE(_TextBase):
+    """CV/Modules/vae_couple.py:374-741."""
+
+    def __init__(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                 WEAtt_type, encoder_emb, decoder_emb, pad_id):
+        super(VAE_COUPLE, self).__init__()
+        self._common(hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                     WEAtt_type, encoder_emb, decoder_emb)
+        self.Encoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        self.PosteriorGaussian = Gaussian(hid_dim * self.n_dir * enc_layers, latent_dim)
+        self.PosteriorGaussianCouple = Gaussian(hid_dim * self.n_dir * enc_layers, latent_dim)
+        self.Decoder = Decoder(**self._dec_kwargs(decoder_emb))
+        self.DecoderCouple = Decoder(**self._dec_kwargs(decoder_emb))
+        self.BoW = nn.Linear(latent_dim, self.voc_size)
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+        self.toInit = nn.Sequential(nn.Linear(latent_dim, self.emb_dim), nn.ReLU(), nn.Linear(self.emb_dim, self.emb_dim))
+        self.toInitCouple = nn.Sequential(nn.Linear(latent_dim, self.emb_dim), nn.ReLU(),
+                                          nn.Linear(self.emb_dim, self.emb_dim))
+
+    def forward(self, go, sent_len=None, bare=None):
+        if not self.training:
+            raise NotImplementedError()
+        last = self.Encoder.last_flat(bare, sent_len)
+        dist, z = self.PosteriorGaussian(last)
+        # the coupled head only uses its mean, but the reference still draws its noise (vae_couple.py:721,801)
+        mu_c, _ = self.PosteriorGaussianCouple.params(last, need_sigma=False)
+        _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
+        init = to_init(self.toInit, z)
+        init_c = to_init(self.toInitCouple, mu_c)
+        logits = self.Decoder(None, init, go, _noise_prefix='dec')
+        logits_c = self.DecoderCouple(None, init_c, go, _noise_prefix='decc')
+        return logits, dist, z, None, logits_c, init, init_c
+
+
+# --------------------------------------------------------------------------- dialogue models
+class _DialogBase(nn.Module):
+    _common = _TextBase._common
+    _dec_kwargs = _TextBase._dec_kwargs
+    _to_init_seq = _TextBase._to_init_seq
+
+    def _encode(self, post_bare, post_len, resp_bare, resp_len):
+        post = self.PostEncoder.last_flat(post_bare, post_len, 'post_enc_drop')
+        post_repr = ops.linear(post, self.PostRepr.weight, self.PostRepr.bias)
+        resp = self.RespEncoder.last_flat(resp_bare, resp_len, 'resp_enc_drop')
+        return post, post_repr, torch.cat([resp, post], dim=1)
+
+    def test_lm(self, post_bare, post_len, resp_go, resp_len, resp_bare, resp_eos, n_sample):
+        """CC/Modules/vae_couple.py:274-364 -> (xent, nll, kl)."""
+        with torch.no_grad():
+            post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len)
+            mu_p, sig_p = self.PriorGaussian.params(post)
+            _noise.normal((1,) + tuple(mu_p.shape), post.device, 'eps_prior')
+            mu, sigma = self.PosteriorGaussian.params(both)
+            _noise.normal((1,) + tuple(mu.shape), post.device, 'eps')
+            xm, nll, kl, _ = _iw_nll(self.Decoder, self._to_init_seq(), resp_go, resp_eos, mu, sigma, mu_p, sig_p,
+                                     post_repr, n_sample, self.criterionSeq.pad)
+            return xm, nll, kl
+
+
+class CVAE(_DialogBase):
+    """CC/Modules/vae.py (class VAE there)."""
+
+    def __init__(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                 WEAtt_type, encoder_emb, decoder_emb, pad_id):
+        super(CVAE, self).__init__()
+        self._common(hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                     WEAtt_type, encoder_emb, decoder_emb)
+        self.PostEncoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        self.RespEncoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        d = hid_dim * self.n_dir * enc_layers
+        self.PriorGaussian = Gaussian(d, latent_dim)
+        self.PosteriorGaussian = Gaussian(2 * d, latent_dim)
+        self.PostRepr = nn.Linear(d, self.emb_dim)
+        self.Decoder = Decoder(with_init=True, **self._dec_kwargs(decoder_emb))
+        self.BoW = nn.Linear(latent_dim, self.voc_size)
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+
+    def forward(self, post_bare, post_len, resp_go, resp_len, resp_bare):
+        if not self.training:
+            raise NotImplementedError()
+        post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len)
+        prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
+        dist, z = self.PosteriorGaussian(both)
+        init = to_init(self.Decoder.toInit, z) + post_repr
+        return self.Decoder(None, init, resp_go), prior, dist
+
+
+class CVAE_COUPLE(_DialogBase):
+    """CC/Modules/vae_couple.py:207-451 (class VAE_COUPLE there)."""
+
+    def __init__(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                 WEAtt_type, encoder_emb, decoder_emb, pad_id):
+        super(CVAE_COUPLE, self).__init__()
+        self._common(hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                     WEAtt_type, encoder_emb, decoder_emb)
+        self.PostEncoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        self.RespEncoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        d = hid_dim * self.n_dir * enc_layers
+        self.PriorGaussian = Gaussian(d, latent_dim)
+        self.PosteriorGaussian = Gaussian(2 * d, latent_dim)
+        self.PosteriorGaussianCouple = Gaussian(2 * d, latent_dim)
+        self.Decoder = Decoder(**self._dec_kwargs(decoder_emb))
+        self.DecoderCouple = Decoder(**self._dec_kwargs(decoder_emb))
+        self.BoW = nn.Linear(latent_dim, self.voc_size)
+        self.PostRepr = nn.Linear(d, self.emb_dim)
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+        self.toInit = nn.Sequential(nn.Linear(latent_dim, self.emb_dim), nn.ReLU(), nn.Linear(self.emb_dim, self.emb_dim))
+        self.toInitCouple = nn.Sequential(nn.Linear(latent_dim, self.emb_dim), nn.ReLU(),
+                                          nn.Linear(self.emb_dim, self.emb_dim))
+
+    def forward(self, post_bare, post_len, resp_go, resp_len, resp_bare):
+        if not self.training:
+            raise NotImplementedError()
+        post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len)
+        prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
+        dist, z = self.PosteriorGaussian(both)
+        mu_c, _ = self.PosteriorGaussianCouple.params(both, need_sigma=False)
+        _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
+        init = to_init(self.toInit, z) + post_repr
+        init_c = to_init(self.toInitCouple, mu_c) + post_repr
+        logits = self.Decoder(None, init, resp_go, _noise_prefix='dec')
+        logits_c = self.DecoderCouple(None, init_c, resp_go, _noise_prefix='decc')
+        return logits, prior, dist, logits_c, init, init_c
+
+
+MODEL_CLASSES = {'vae': VAE, 'vae-couple': VAE_COUPLE, 'cvae': CVAE, 'cvae-couple': CVAE_COUPLE}

@@ -1,0 +1,374 @@
+"""torch.autograd wrappers around the C ABI (one Function per reference function on the path).
+
+torch is plumbing here: it owns device memory, the stream and the autograd tape; every
+number is produced by libcvae_hip kernels.  All tensors are fp32 / int64 on the GPU.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, ptr_array, query, stream
+
+GRU, LSTM = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_EXP = 0, 1, 2, 3
+
+
+def _f(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def gates_of(cell):
+    return 3 if cell == GRU else 4
+
+
+# --------------------------------------------------------------------------- a1 / a2
+def pack_batch(raw_flat, raw_offsets, max_len, width, pad=0, go=1, eos=2):
+    """CV/dataloaders/ptb.py:118-129 + Experiment.py:659-664 on device."""
+    B = raw_offsets.numel() - 1
+    dev = raw_flat.device
+    bare = torch.empty((B, width), dtype=torch.int64, device=dev)
+    go_t = torch.empty((B, width + 1), dtype=torch.int64, device=dev)
+    eos_t = torch.empty((B, width + 1), dtype=torch.int64, device=dev)
+    ln = torch.empty((B,), dtype=torch.int64, device=dev)
+    call('cvae_pack_batch', ptr(raw_flat), ptr(raw_offsets), B, max_len, width, pad, go, eos, ptr(bare), ptr(go_t),
+         ptr(eos_t), ptr(ln), stream())
+    return bare, go_t, eos_t, ln
+
+
+def sort_resort(length):
+    """CV/utils/utils.py:18-21 on device -> (s_idx, res_idx) int64 tensors."""
+    length = _c(length)
+    B = length.numel()
+    s_idx = torch.empty_like(length)
+    res_idx = torch.empty_like(length)
+    call('cvae_sort_resort', ptr(length), B, ptr(s_idx), ptr(res_idx), stream())
+    return s_idx, res_idx
+
+
+def gemm(A, B, transA=False, transB=False, bias=None, act=ACT_NONE, out=None, beta=0):
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    if out is None:
+        out = _f((M, N), A)
+    call('cvae_gemm', int(transA), int(transB), M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out),
+         out.stride(0), ptr(bias), act, beta, stream())
+    return out
+
+
+# --------------------------------------------------------------------------- linear
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        x, W, b = _c(x), _c(W), _c(b)
+        M, K = x.shape
+        N = W.shape[0]
+        y = _f((M, N), x)
+        call('cvae_linear_forward', ptr(x), ptr(W), ptr(b), act, M, N, K, ptr(y), stream())
+        ctx.act = act
+        ctx.save_for_backward(x, W, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N = W.shape[0]
+        dx = _f((M, K), x) if ctx.needs_input_grad[0] else None
+        dW, db = torch.empty_like(W), _f((N,), x)
+        scratch = _f((M, N), x) if ctx.act != ACT_NONE else None
+        call('cvae_linear_backward', ptr(x), ptr(W), ptr(y), ptr(dy), ctx.act, M, N, K, ptr(dx), ptr(dW), ptr(db),
+             ptr(scratch), stream())
+        return dx, dW, db, None
+
+
+def linear(x, W, b, act=ACT_NONE):
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), W, b, act)
+    return y.reshape(*lead, W.shape[0])
+
+
+# --------------------------------------------------------------------------- encoder
+class EncoderFn(torch.autograd.Function):
+    """CV/Modules/encoder.py:41-70 -> last states (B, 2H)."""
+
+    @staticmethod
+    def forward(ctx, cell, ids, length, mask, mask_rows, emb, *w):
+        ids, length, emb = _c(ids), _c(length), _c(emb)
+        w = [_c(t) for t in w]
+        B, Lmax = ids.shape
+        V, E = emb.shape
+        H = w[1].shape[1]
+        G = gates_of(cell)
+        need_grad = any(ctx.needs_input_grad)
+        X = _f((Lmax, B, E), emb)
+        xproj = _f((2, Lmax, B, G * H), emb)
+        hs = _f((2, Lmax + 1, B, H), emb)
+        cs = _f((2, Lmax + 1, B, H), emb) if cell == LSTM else None
+        gates = _f((2, Lmax, B, 4 * H), emb) if need_grad else None
+        last = _f((B, 2 * H), emb)
+        warr = ptr_array(w)
+        call('cvae_encoder_forward', cell, B, Lmax, E, H, V, ptr(ids), ptr(length), ptr(emb), ptr(mask),
+             ptr(mask_rows), warr, ptr(X), ptr(xproj), ptr(hs), ptr(cs), ptr(gates), ptr(last), stream())
+        if need_grad:
+            ctx.cell, ctx.dims = cell, (B, Lmax, E, H, V)
+            ctx.save_for_backward(ids, length, mask, mask_rows, emb, X, hs, cs, gates, *w)
+        return last
+
+    @staticmethod
+    def backward(ctx, dlast):
+        ids, length, mask, mask_rows, emb, X, hs, cs, gates = ctx.saved_tensors[:9]
+        w = list(ctx.saved_tensors[9:])
+        B, Lmax, E, H, V = ctx.dims
+        dlast = _c(dlast)
+        dw = [torch.empty_like(t) for t in w]
+        demb = torch.zeros_like(emb)
+        scratch = _f((query('cvae_encoder_backward_scratch', ctx.cell, B, Lmax, E, H),), emb)
+        warr, dwarr = ptr_array(w), ptr_array(dw)
+        call('cvae_encoder_backward', ctx.cell, B, Lmax, E, H, V, ptr(ids), ptr(length), ptr(mask), ptr(mask_rows),
+             warr, ptr(X), ptr(hs), ptr(cs), ptr(gates), ptr(dlast), dwarr, ptr(demb), ptr(scratch), stream())
+        return (None, None, None, None, None, demb, *dw)
+
+
+def encoder(cell, ids, length, mask, mask_rows, emb, w):
+    """w: [W_ih, W_hh, b_ih, b_hh, W_ih_r, W_hh_r, b_ih_r, b_hh_r]."""
+    return EncoderFn.apply(cell, ids, length, mask, mask_rows, emb, *w)
+
+
+# --------------------------------------------------------------------------- decoder
+class DecoderFn(torch.autograd.Function):
+    """Teacher-forced decoder up to `final` (T,R,E): CV/Modules/vae_couple.py:86-115."""
+
+    @staticmethod
+    def forward(ctx, cell, train, init, go, mask_in, mask_out, emb, *w):
+        init, go, emb = _c(init), _c(go), _c(emb)
+        w = [_c(t) for t in w]
+        R, E = init.shape
+        B, T = go.shape
+        V = emb.shape[0]
+        Hd = w[1].shape[1]
+        G = gates_of(cell)
+        big = R > 256
+        hs = _f((T + 2, R, Hd), emb)
+        cs = _f((T + 2, R, Hd), emb) if cell == LSTM else None
+        final = _f((T, R, E), emb)
+        hp = _f((R, G * Hd), emb) if big else None
+        if train:
+            X = _f((T + 1, R, 2 * E), emb)
+            xproj = _f((T + 1, R, G * Hd), emb)
+            xadd = None
+            gates = _f((T + 1, R, 4 * Hd), emb)
+            hdrop = _f((T, R, Hd), emb) if mask_out is not None else None
+        else:
+            X = _f((T, B, E), emb)
+            xproj = _f((T, B, G * Hd), emb)
+            xadd = _f((2, R, G * Hd), emb)
+            gates = hdrop = None
+        warr = ptr_array(w)
+        call('cvae_decoder_forward', cell, int(train), B, R, T, E, Hd, V, ptr(init), ptr(go), ptr(emb), ptr(mask_in),
+             ptr(mask_out), warr, ptr(X), ptr(xproj), ptr(xadd), ptr(hp), ptr(hs), ptr(cs), ptr(gates), ptr(hdrop),
+             ptr(final), stream())
+        if train:
+            ctx.cell, ctx.dims = cell, (B, T, E, Hd, V)
+            ctx.save_for_backward(go, mask_in, mask_out, emb, X, hs, cs, gates, hdrop, final, *w)
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal):
+        go, mask_in, mask_out, emb, X, hs, cs, gates, hdrop, final = ctx.saved_tensors[:10]
+        w = list(ctx.saved_tensors[10:])
+        B, T, E, Hd, V = ctx.dims
+        dfinal = _c(dfinal)
+        dinit = _f((B, E), emb)
+        dw = [torch.empty_like(t) for t in w]
+        demb = torch.zeros_like(emb)
+        scratch = _f((query('cvae_decoder_backward_scratch', ctx.cell, B, T, E, Hd),), emb)
+        warr, dwarr = ptr_array(w), ptr_array(dw)
+        call('cvae_decoder_backward', ctx.cell, B, T, E, Hd, V, ptr(go), ptr(mask_in), ptr(mask_out), warr, ptr(X),
+             ptr(hs), ptr(cs), ptr(gates), ptr(hdrop), ptr(final), ptr(dfinal), ptr(dinit), dwarr, ptr(demb),
+             ptr(scratch), stream())
+        return (None, None, dinit, None, None, None, demb, *dw)
+
+
+def decoder(cell, train, init, go, mask_in, mask_out, emb, w):
+    """w: [W_ih, W_hh, b_ih, b_hh, W_c, b_c] -> final (T,R,E)."""
+    if not train:
+        with torch.no_grad():
+            return DecoderFn.apply(cell, False, init, go, None, None, emb, *w)
+    return DecoderFn.apply(cell, True, init, go, mask_in, mask_out, emb, *w)
+
+
+# --------------------------------------------------------------------------- projection + CE
+def targets_time_major(eos, R):
+    eos = _c(eos)
+    B, T = eos.shape
+    out = torch.empty((T * R,), dtype=torch.int64, device=eos.device)
+    call('cvae_targets_time_major', ptr(eos), B, T, R, ptr(out), stream())
+    return out
+
+
+class ProjCEFn(torch.autograd.Function):
+    """ToVocab + SeqLoss(keep_batch=True): per-sentence summed CE (R,), logits never stored."""
+
+    @staticmethod
+    def forward(ctx, final, W, b, tgt_tm, pad):
+        final, W, b = _c(final), _c(W), _c(b)
+        T, R, E = final.shape
+        V = W.shape[0]
+        N = T * R
+        loss_row, lse, sent = _f((N,), final), _f((N,), final), _f((R,), final)
+        ws = _f((query('cvae_projce_workspace', N, V),), final)
+        call('cvae_projce_forward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, T, R, E, V, ptr(loss_row), ptr(lse),
+             ptr(sent), ptr(ws), stream())
+        ctx.pad = pad
+        ctx.save_for_backward(final, W, b, tgt_tm, lse)
+        return sent
+
+    @staticmethod
+    def backward(ctx, gsent):
+        final, W, b, tgt_tm, lse = ctx.saved_tensors
+        T, R, E = final.shape
+        V = W.shape[0]
+        gsent = _c(gsent)
+        dfinal, dW, db = torch.empty_like(final), torch.empty_like(W), torch.empty_like(b)
+        ws = _f((query('cvae_projce_backward_workspace', T * R, V),), final)
+        call('cvae_projce_backward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent), T, R, E, V,
+             ptr(dfinal), ptr(dW), ptr(db), ptr(ws), stream())
+        return dfinal, dW, db, None, None
+
+
+def proj_ce(final, W, b, eos, pad):
+    """final (T,R,E), eos (B,T) with R % B == 0 -> (R,)."""
+    tgt = targets_time_major(eos, final.shape[1])
+    return ProjCEFn.apply(final, W, b, tgt, pad)
+
+
+def logits_bt(final, W, b):
+    """Materialised (B,T,V) logits for callers that index them (not the hot path)."""
+    final, W, b = _c(final), _c(W), _c(b)
+    T, B, E = final.shape
+    V = W.shape[0]
+    tmp, out = _f((T * B, V), final), _f((B, T, V), final)
+    call('cvae_logits', ptr(final), ptr(W), ptr(b), T, B, E, V, ptr(tmp), ptr(out), stream())
+    return out
+
+
+# --------------------------------------------------------------------------- latent space
+class ReparamFn(torch.autograd.Function):
+    """z = mu + sigma * eps  (Normal.rsample, CV/Modules/vae_couple.py:801)."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, eps):
+        mu, sigma, eps = _c(mu), _c(sigma), _c(eps)
+        B, Z = mu.shape
+        z = torch.empty_like(mu)
+        call('cvae_reparam_forward', ptr(mu), ptr(sigma), ptr(eps), 1, B, Z, ptr(z), stream())
+        ctx.save_for_backward(eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        eps, = ctx.saved_tensors
+        dz = _c(dz)
+        B, Z = dz.shape
+        dmu, dsigma = torch.zeros_like(dz), torch.zeros_like(dz)
+        call('cvae_reparam_backward', ptr(dz), ptr(eps), B, Z, ptr(dmu), ptr(dsigma), stream())
+        return dmu, dsigma, None
+
+
+def rsample_n(mu, sigma, eps):
+    """eps (n,B,Z) -> z (n,B,Z), no autograd (eval)."""
+    mu, sigma, eps = _c(mu), _c(sigma), _c(eps)
+    n, B, Z = eps.shape
+    z = torch.empty_like(eps)
+    call('cvae_reparam_forward', ptr(mu), ptr(sigma), ptr(eps), n, B, Z, ptr(z), stream())
+    return z
+
+
+class KLFn(torch.autograd.Function):
+    """kl_divergence(N(mu,sigma) || prior).sum(1) -> (B,)."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, mu_p, sigma_p):
+        mu, sigma, mu_p, sigma_p = _c(mu), _c(sigma), _c(mu_p), _c(sigma_p)
+        B, Z = mu.shape
+        kl = _f((B,), mu)
+        call('cvae_kl_forward', ptr(mu), ptr(sigma), ptr(mu_p), ptr(sigma_p), B, Z, ptr(kl), stream())
+        ctx.save_for_backward(mu, sigma, mu_p, sigma_p)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        mu, sigma, mu_p, sigma_p = ctx.saved_tensors
+        gkl = _c(gkl)
+        B, Z = mu.shape
+        dmu, dsigma = torch.empty_like(mu), torch.empty_like(mu)
+        dmu_p = torch.empty_like(mu) if mu_p is not None else None
+        dsigma_p = torch.empty_like(mu) if mu_p is not None else None
+        call('cvae_kl_backward', ptr(mu), ptr(sigma), ptr(mu_p), ptr(sigma_p), ptr(gkl), B, Z, ptr(dmu), ptr(dsigma),
+             ptr(dmu_p), ptr(dsigma_p), stream())
+        return dmu, dsigma, dmu_p, dsigma_p
+
+
+def kl_div(mu, sigma, mu_p=None, sigma_p=None):
+    return KLFn.apply(mu, sigma, mu_p, sigma_p)
+
+
+class CoupleFn(torch.autograd.Function):
+    """euclidean(init, init_c.detach()) [+ IMQ]: CV/Experiment.py:742-751,1892-1923 -> (B,)."""
+
+    @staticmethod
+    def forward(ctx, init, init_c, Z, euclid):
+        init, init_c = _c(init), _c(init_c.detach())
+        B, E = init.shape
+        d, loss = _f((B,), init), _f((B,), init)
+        call('cvae_couple_forward', ptr(init), ptr(init_c), B, E, Z, int(euclid), ptr(d), ptr(loss), stream())
+        ctx.Z, ctx.euclid = Z, int(euclid)
+        ctx.save_for_backward(init, init_c, d)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        init, init_c, d = ctx.saved_tensors
+        g = _c(g)
+        B, E = init.shape
+        dinit = torch.empty_like(init)
+        call('cvae_couple_backward', ptr(init), ptr(init_c), ptr(d), ptr(g), B, E, ctx.Z, ctx.euclid, ptr(dinit),
+             stream())
+        return dinit, None, None, None
+
+
+def couple_loss(init, init_c, latent_dim, euclidean_dist):
+    return CoupleFn.apply(init, init_c, latent_dim, euclidean_dist)
+
+
+# --------------------------------------------------------------------------- IW / MI
+def iw_reduce(z, xent, mu, sigma, mu_p=None, sigma_p=None):
+    z, xent, mu, sigma, mu_p, sigma_p = _c(z), _c(xent), _c(mu), _c(sigma), _c(mu_p), _c(sigma_p)
+    K, B, Z = z.shape
+    nll, kl, xm = _f((B,), z), _f((B,), z), _f((B,), z)
+    call('cvae_iw_reduce', ptr(z), ptr(xent), ptr(mu), ptr(sigma), ptr(mu_p), ptr(sigma_p), K, B, Z, ptr(nll), ptr(kl),
+         ptr(xm), stream())
+    return xm, nll, kl
+
+
+def mi(z, mu, sigma):
+    z, mu, sigma = _c(z), _c(mu), _c(sigma)
+    K, B, Z = z.shape
+    out = _f((B,), z)
+    ws = _f((2 * K * B,), z)
+    call('cvae_mi', ptr(z), ptr(mu), ptr(sigma), K, B, Z, ptr(ws), ptr(out), stream())
+    return out
+
+
+# --------------------------------------------------------------------------- optimizer
+def clip_adam(params, grads, m, v, alias_off, alias_n, alias_mult, max_norm, lr, betas, eps, step_other, step_alias,
+              sumsq, norm_out):
+    call('cvae_clip_adam', ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), alias_off, alias_n, alias_mult,
+         max_norm, lr, betas[0], betas[1], eps, step_other, step_alias, ptr(sumsq), ptr(norm_out), stream())

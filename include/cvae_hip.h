@@ -1,0 +1,176 @@
+/* libcvae_hip: C ABI of the MI355X (gfx950) hot path of Coupled-VAE.
+ *
+ * The reference has no FFI: its hot path is Python on torch.  The entry
+ * points below are what a binding for that path binds: one call per reference function on
+ * the path (forward and, for training, its backward), citing the reference code replaced.
+ * CV = /root/reference/Coupled-VAE, CC = /root/reference/Coupled-CVAE.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; float = fp32, ids = int64.
+ *  - row-major, contiguous tensors; sequences are time-major inside the library: (T, B, .).
+ *  - `stream` is a hipStream_t (NULL = default stream); all work is enqueued, nothing syncs.
+ *  - return 0 on success, negative on error; cvae_last_error() returns the message
+ *    (thread-local).  Shape / pointer preconditions are checked on the host before launch.
+ *  - nothing here allocates: workspaces are passed in by the caller.
+ *  - cell: 0 = GRU (gate rows r,z,n), 1 = LSTM (i,f,g,o), PyTorch equations and layouts.
+ *    G = 3 or 4 below.
+ */
+#ifndef CVAE_HIP_H
+#define CVAE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int cvae_version(void);
+const char* cvae_last_error(void);
+/* Checks that `device` is a gfx950 part and makes it current. */
+int cvae_init(int device);
+
+/* ---- a1: batch layout.  dataloaders/ptb.py:118-129 (process_raw_sent) + the truncation
+ * to the batch maximum of Experiment.py:659-664.  raw_flat/raw_offsets: CSR token ids of B
+ * sentences.  Sentences are cut at max_len; rows are right-padded with `pad` to `width`
+ * (bare) / width+1 (go, eos).  width = max_len for the un-truncated eval layout, or
+ * min(max_len, longest sentence) for the training layout. */
+int cvae_pack_batch(const int64_t* raw_flat, const int64_t* raw_offsets, int B, int max_len, int width,
+                    int64_t pad, int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out,
+                    int64_t* len, void* stream);
+/* ---- a2: utils/utils.py:18-21 (sort_resort): stable descending order and its inverse. */
+int cvae_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, void* stream);
+
+/* ---- generic fp32 MFMA product  C = act(op(A) op(B) + bias) (+ C);  nn.Linear / F.linear.
+ * transA=0: A[M,K] (lda) ; 1: A[K,M].  transB=0: B[K,N] (ldb) ; 1: B[N,K].
+ * act: 0 none, 1 tanh, 2 relu, 3 exp.  beta: 0 overwrite, 1 accumulate. */
+int cvae_gemm(int transA, int transB, int M, int N, int K, const float* A, int64_t lda, const float* B,
+              int64_t ldb, float* C, int64_t ldc, const float* bias, int act, int beta, void* stream);
+/* y = act(x W^T + b): Gaussian heads (vae_couple.py:798-799), toInit (:429-434), PostRepr
+ * (CC vae_couple.py:263).  x[M,K] W[N,K] b[N] y[M,N]. */
+int cvae_linear_forward(const float* x, const float* W, const float* b, int act, int M, int N, int K, float* y,
+                        void* stream);
+/* Backward of the above.  dy[M,N] is upstream; y is the forward output (needed for act != 0).
+ * dx[M,K] (nullable) is overwritten, dW[N,K] and db[N] are overwritten.  scratch: M*N floats. */
+int cvae_linear_backward(const float* x, const float* W, const float* y, const float* dy, int act, int M, int N,
+                         int K, float* dx, float* dW, float* db, float* scratch, void* stream);
+
+/* ---- a3: Encoder.forward (Modules/encoder.py:41-70), bidirectional 1-layer GRU/LSTM over
+ * packed sequences, returning only what callers consume: last[B,2H] = [h_fwd | h_bwd].
+ * ids[B,L]; len[B]; emb[V,E]; mask: NULL (eval) or the dropout mask (L,B,E) with values
+ * {0, 1/(1-p)}; mask_rows: NULL or int64[B], column of `mask` that batch row b uses (the
+ * reference draws the mask in length-sorted order: pass res_idx of cvae_sort_resort).
+ * w[8] = {W_ih, W_hh, b_ih, b_hh, W_ih_reverse, W_hh_reverse, b_ih_reverse, b_hh_reverse}.
+ * Saved for backward (all caller-allocated): X[L,B,E], xproj[2][L,B,G*H], hs[2][(L+1),B,H],
+ * cs[2][(L+1),B,H] (LSTM, else NULL), gates[2][L,B,4H] (NULL in eval: nothing saved). */
+int cvae_encoder_forward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
+                         const float* emb, const float* mask, const int64_t* mask_rows, const float* const* w,
+                         float* X, float* xproj, float* hs, float* cs, float* gates, float* last, void* stream);
+/* dlast[B,2H] -> dw[8] (same order as w, overwritten), demb[V,E] (ACCUMULATED into).
+ * scratch: floats, at least cvae_encoder_backward_scratch(cell,B,L,E,H). */
+int64_t cvae_encoder_backward_scratch(int cell, int B, int L, int E, int H);
+int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
+                          const float* mask, const int64_t* mask_rows, const float* const* w, const float* X,
+                          const float* hs, const float* cs, const float* gates, const float* dlast,
+                          float* const* dw, float* demb, float* scratch, void* stream);
+
+/* ---- a7: Decoder.forward, teacher-forcing branch (Modules/vae_couple.py:86-115,
+ * Modules/decoder.py:85-107) up to final = tanh(W_c drop(h_t)) -- the vocab projection is
+ * fused into the loss (cvae_projce_*).  R rows = B (training) or n_sample*B (IW eval);
+ * init[R,E]; go[B,T] ids shared by the R/B row groups (row r decodes sentence r % B).
+ * mask_in (T,R,2E) / mask_out (T,R,Hd): NULL in eval.  w[6] = {W_ih[G*Hd,2E], W_hh, b_ih,
+ * b_hh, W_c[E,Hd], b_c[E]}.  Step 0 of the internal (T+1)-step sequence is the prefix step
+ * h_0 = RNN([init,init], 0) (:96-103).
+ * train != 0: saves X[(T+1),R,2E], xproj[(T+1),R,G*Hd], hs[(T+2),R,Hd], cs (LSTM), gates
+ *   [(T+1),R,4Hd], hdrop[T,R,Hd]; requires R == B.
+ * train == 0: exact eval dedup (SURVEY 7 "IW eval savings"): the emb(go_t) half of the input
+ *   projection is computed once per sentence and the init half once per row; X is then
+ *   [T,B,E] scratch, xproj [T,B,G*Hd], xadd[2,R,G*Hd], hp[R,G*Hd] scratch (R > 256),
+ *   gates NULL.
+ * final[T,R,E] out. */
+int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd, int64_t V, const float* init,
+                         const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
+                         const float* const* w, float* X, float* xproj, float* xadd, float* hp, float* hs,
+                         float* cs, float* gates, float* hdrop, float* final, void* stream);
+int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd);
+/* dfinal[T,B,E] -> dinit[B,E] (overwritten), dw[6] (overwritten), demb[V,E] (ACCUMULATED). */
+int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                          const float* mask_in, const float* mask_out, const float* const* w, const float* X,
+                          const float* hs, const float* cs, const float* gates, const float* hdrop,
+                          const float* final, const float* dfinal, float* dinit, float* const* dw, float* demb,
+                          float* scratch, void* stream);
+
+/* ---- a7 tail + a8: ToVocab + SeqLoss(keep_batch=True) (Modules/vae_couple.py:119,
+ * Modules/Losses/SeqLoss.py:36-44), fused: logits are never materialised.
+ * final[T*R,E] (time-major rows n = t*R + r), W[V,E], b[V], tgt[T*R] (time-major targets),
+ * -> loss_row[T*R] (0 where tgt == pad), lse[T*R], sent[R] = sum over t.
+ * ws: cvae_projce_workspace(T*R, V) floats. */
+int64_t cvae_projce_workspace(int64_t N, int64_t V);
+int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                        int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent, float* ws,
+                        void* stream);
+/* gsent[R] = dL/dsent.  dfinal[T*R,E] overwritten; dW[V,E], db[V] overwritten.
+ * ws: cvae_projce_backward_workspace(T*R, V) floats. */
+int64_t cvae_projce_backward_workspace(int64_t N, int64_t V);
+int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                         const float* lse, const float* gsent, int T, int R, int E, int64_t V, float* dfinal,
+                         float* dW, float* db, float* ws, void* stream);
+/* tgt_tm[t*R + r] = eos[(r % B)*T + t]: time-major targets for R = n*B rows. */
+int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream);
+/* Materialise logits[B,T,V] (batch-major, as the reference returns them) for callers that
+ * index them; not used on the hot path. */
+int cvae_logits(const float* final, const float* W, const float* b, int T, int B, int E, int64_t V, float* tmp,
+                float* logits, void* stream);
+
+/* ---- a5: rsample (Modules/vae_couple.py:801): z[n,b,:] = mu[b,:] + sigma[b,:]*eps[n,b,:]. */
+int cvae_reparam_forward(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
+                         void* stream);
+/* dz[B,Z] (n = 1) -> dmu += dz, dsigma += dz*eps (both ACCUMULATED). */
+int cvae_reparam_backward(const float* dz, const float* eps, int B, int Z, float* dmu, float* dsigma,
+                          void* stream);
+/* ---- a9: kl_divergence(N(mu,sigma) || N(mu_p,sigma_p)).sum(1) (Experiment.py:733-735;
+ * CC Experiment.py:398-399).  mu_p = sigma_p = NULL means the standard normal. -> kl[B]. */
+int cvae_kl_forward(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, int B, int Z,
+                    float* kl, void* stream);
+/* gkl[B] upstream -> dmu, dsigma (overwritten), dmu_p, dsigma_p (overwritten, nullable). */
+int cvae_kl_backward(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
+                     const float* gkl, int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p,
+                     void* stream);
+/* ---- a10: euclidean + compute_imq_dist_couple (Experiment.py:742-751,1892-1923).
+ * euclid != 0: loss[b] = d ; else loss[b] = -sum_s C_s/(C_s+d), C_s = 2*Z*s.  d[b] also out. */
+int cvae_couple_forward(const float* init, const float* init_c, int B, int E, int Z, int euclid, float* d,
+                        float* loss, void* stream);
+/* gloss[B] -> dinit[B,E] (init_c is detached in the reference: no gradient). */
+int cvae_couple_backward(const float* init, const float* init_c, const float* d, const float* gloss, int B,
+                         int E, int Z, int euclid, float* dinit, void* stream);
+
+/* ---- a13/a14: importance_sampling tail (Modules/vae_couple.py:558-578; log_sum_exp
+ * utils/utils.py:69-82).  z[K,B,Z], xent[K,B] = -log p(x|z), posterior (mu,sigma)[B,Z],
+ * prior (mu_p,sigma_p)[B,Z] or NULL (standard normal) ->
+ *   nll[b] = -(LSE_k(log p(z) - xent - log q(z|x)) - log K), kl[b] = mean_k(log q - log p),
+ *   xent_mean[b] = mean_k xent. */
+int cvae_iw_reduce(const float* z, const float* xent, const float* mu, const float* sigma, const float* mu_p,
+                   const float* sigma_p, int K, int B, int Z, float* nll, float* kl, float* xent_mean,
+                   void* stream);
+/* ---- a15: importance_sampling_mi (Modules/vae_couple.py:471-502).  z[K,B,Z] -> mi[B].
+ * The (K,B,B) pairwise tensor is never formed.  ws: 2*K*B floats. */
+int cvae_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* ws, float* mi,
+            void* stream);
+
+/* ---- a12: clip_grad_norm_ + Adam over a flat parameter arena
+ * (Experiment.py:509-522,596-599), with the reference's duplicate-listing behaviour: the
+ * segment [alias_off, alias_off+alias_n) (the shared embedding) is listed `alias_mult`
+ * times: its squared norm counts that many times, its gradient is scaled by coef^mult and it
+ * takes `alias_mult` Adam steps per call (step counter kept by the caller: step_other for
+ * the rest, step_alias = value BEFORE this call for the alias segment).
+ * sumsq: 2 floats of device scratch.  params/grads/m/v: n floats each. */
+int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
+                   int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
+                   float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
+                   void* stream);
+
+/* small helpers used by the host mirror */
+int cvae_sum_time(const float* x, int T, int R, float* out, void* stream);       /* out[r] = sum_t x[t,r] */
+int cvae_axpy(const float* x, float a, int64_t n, float* y, void* stream);       /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/cvae_hip.h
+declares (with the arity the ctypes binding uses), and the host mirror exposes the
+reference's state_dict contract.  No compute calls: there is no GPU here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from golden_util import Golden, names
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'cvae_hip.h')
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|int64_t|const char\*)\s+(cvae_\w+)\s*\(([^;]*?)\)\s*;', src, re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ('', 'void') else len([a for a in args.split(',') if a.strip()])
+        out[m.group(1)] = n
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from cvae_amd import _lib
+    decl = declared_functions()
+    assert len(decl) >= 30
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name, nargs in decl.items():
+        assert hasattr(so, name), 'libcvae_hip.so does not export %s' % name
+        if name == 'cvae_last_error':
+            continue
+        assert name in _lib.SIGNATURES, 'binding missing for %s' % name
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
+    assert set(_lib.SIGNATURES) <= set(decl)
+
+
+def test_init_fails_loudly_without_gpu():
+    from cvae_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.CvaeHipError):
+        _lib.call('cvae_init', 0)
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, 'coupled-vae_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.hpp', '.cpp')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in txt.replace('# oracle', ''), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize('name', names())
+def test_state_dict_contract(name):
+    """Keys, order and shapes equal the reference's state_dict, incl. alias count."""
+    from cvae_amd import harness
+    g = Golden(name)
+    m = g.meta
+    hp = harness.HParams(model=m['model'], cell=m['cell'], V=m['V'], E=m['E'], H=m['H'], Z=m['Z'])
+    model = harness.build_model(hp, 'cpu', seed=0)
+    sd = model.state_dict()
+    assert list(sd.keys()) == m['state_keys']
+    for k in m['state_keys']:
+        assert tuple(sd[k].shape) == tuple(g.np('init/' + k).shape), k
+    sdk = model.state_dict(keep_vars=True)
+    trainable = [v for v in sdk.values() if v.requires_grad]
+    assert len(trainable) == m['trainable_entries']
+    assert len({id(v) for v in trainable}) == m['trainable_unique']
+    model.load_state_dict({k: g.t('init/' + k) for k in m['state_keys']}, strict=True)
+
+
+def test_lambda_kl_matches_reference_formula():
+    from cvae_amd import harness
+    hp = harness.HParams()
+    assert harness.lambda_kl(1, hp) == 0.0
+    assert harness.lambda_kl(22000, hp) == 0.5
+    assert harness.lambda_kl(2001, hp) == 2.5e-05
+    assert harness.lambda_kl(10 ** 7, hp) == 1.0

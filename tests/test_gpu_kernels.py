@@ -1,0 +1,318 @@
+"""Per-kernel numerics on a real MI355X, through the C ABI (ctypes), against fp64 torch /
+the CPU oracle.  Tolerances: fp32 contractions 2e-5 relative to max|ref| (exact-f32 MFMA
+chains), everything integer bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cvae_oracle as O   # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from cvae_amd import _lib
+    _lib.init(0)
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+GEMM_CASES = [
+    # M, N, K, transA, transB, bias, act, beta
+    (5, 50, 16, 0, 1, 1, 0, 0),            # tiny, scalar tails
+    (7, 13, 9, 0, 0, 0, 0, 0),             # unaligned everything
+    (32, 1536, 512, 0, 1, 1, 0, 0),        # skinny (M<=64), K split over waves
+    (32, 512, 1536, 0, 0, 0, 0, 1),        # skinny, B not transposed, accumulate (RNN backward shape)
+    (64, 200, 32, 0, 1, 1, 2, 0),          # toInit shape: K < 64 -> tiled 64x64, relu
+    (300, 200, 400, 0, 1, 1, 1, 0),        # tiled 64x64, tanh
+    (2912, 1536, 400, 0, 1, 1, 0, 0),      # decoder input projection (Yelp train): 128x128 tiles
+    (1536, 400, 2912, 1, 0, 0, 0, 0),      # weight gradient dW = dG^T X
+    (2912, 400, 1536, 0, 0, 0, 0, 0),      # input gradient dX = dG W
+    (100, 64, 5000, 0, 0, 0, 0, 0),        # few tiles, long K -> split-K with atomics
+    (100, 64, 5000, 0, 0, 0, 0, 1),        # split-K accumulate
+    (130, 70, 33, 1, 1, 1, 3, 0),          # both transposed, exp
+    (1, 1, 1, 0, 1, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize('case', GEMM_CASES)
+def test_gemm(dev, case):
+    from cvae_amd import ops
+    M, N, K, tA, tB, bias, act, beta = case
+    A = rnd(*((K, M) if tA else (M, K)), dev=dev, seed=1)
+    B = rnd(*((N, K) if tB else (K, N)), dev=dev, seed=2)
+    if act == 3:
+        A = A * 0.1
+    b = rnd(N, dev=dev, seed=3) if bias else None
+    C0 = rnd(M, N, dev=dev, seed=4)
+    out = C0.clone()
+    ops.gemm(A, B, bool(tA), bool(tB), b, act, out=out, beta=beta)
+    Ad, Bd = A.double(), B.double()
+    ref = (Ad.t() if tA else Ad) @ (Bd.t() if tB else Bd)
+    if bias:
+        ref = ref + b.double()
+    ref = {0: lambda x: x, 1: torch.tanh, 2: torch.relu, 3: torch.exp}[act](ref)
+    if beta:
+        ref = ref + C0.double()
+    assert rel(out, ref) < 2e-5, case
+
+
+def test_gemm_strided_operands(dev):
+    """Sub-matrix views (the decoder reads the two column halves of W_ih)."""
+    from cvae_amd import ops
+    W = rnd(96, 80, dev=dev)
+    x = rnd(70, 40, dev=dev, seed=5)
+    out = ops.gemm(x, W[:, 40:], False, True)
+    assert rel(out, x.double() @ W[:, 40:].double().t()) < 2e-5
+
+
+def test_pack_batch_and_sort_bit_exact(dev):
+    from cvae_amd import ops
+    rs = np.random.RandomState(0)
+    sents = [rs.randint(4, 50, size=n).tolist() for n in (3, 12, 15, 1, 7, 12, 20)]
+    max_len = 12
+    for truncate in (False, True):
+        bare, go, eos, ln = O.make_batch(sents, max_len, truncate=truncate)
+        flat = torch.tensor([t for s in sents for t in s], dtype=torch.int64, device=dev)
+        off = torch.tensor(np.cumsum([0] + [len(s) for s in sents]), dtype=torch.int64, device=dev)
+        width = bare.shape[1]
+        got = ops.pack_batch(flat, off, max_len, width)
+        for g, r in zip(got, (bare, go, eos, ln)):
+            assert g.dtype == torch.int64 and np.array_equal(g.cpu().numpy(), r)
+    for lens in ([7, 3, 5, 3, 1], [2, 2, 2], [1], [4, 9, 9, 1, 4, 9, 2], list(rs.randint(1, 9, size=300))):
+        s, r = ops.sort_resort(torch.tensor(lens, dtype=torch.int64, device=dev))
+        s_ref, r_ref = O.sort_resort(lens)
+        assert s.tolist() == s_ref and r.tolist() == r_ref
+
+
+def _rnn_params(cell, inp, hid, bi, seed):
+    G = 3 if cell == 'gru' else 4
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / math.sqrt(hid)
+    ws = []
+    for _ in range(2 if bi else 1):
+        ws += [(torch.rand(G * hid, inp, generator=g) * 2 - 1) * k, (torch.rand(G * hid, hid, generator=g) * 2 - 1) * k,
+               (torch.rand(G * hid, generator=g) * 2 - 1) * k, (torch.rand(G * hid, generator=g) * 2 - 1) * k]
+    return ws
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+@pytest.mark.parametrize('shape', [(5, 7, 16, 8, 50), (32, 40, 200, 128, 1000)])
+def test_encoder_forward_backward(dev, cell, shape):
+    """Packed bi-RNN last states + every gradient vs the oracle in fp64."""
+    from cvae_amd import ops
+    B, L, E, H, V = shape
+    g = torch.Generator().manual_seed(1)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    if B > 3:
+        lens[1] = lens[2]                                    # ties
+    ids = torch.randint(0, V, (B, L), generator=g)
+    emb = torch.randn(V, E, generator=g)
+    ws = _rnn_params(cell, E, H, True, 2)
+    mask = (torch.rand(L, B, E, generator=g) > 0.2).float() / 0.8
+    dlast = torch.randn(B, 2 * H, generator=g)
+    # oracle, fp64
+    cn = 'GRU' if cell == 'gru' else 'LSTM'
+    P = {'Enc.Embedding.weight': emb.double().requires_grad_(True)}
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    for d, suf in enumerate(['', '_reverse']):
+        for j, n in enumerate(names):
+            P['Enc.%s.%s%s' % (cn, n, suf)] = ws[4 * d + j].double().requires_grad_(True)
+    ref = O.encoder(P, 'Enc.', cell, ids, lens, mask.double())
+    (ref * dlast.double()).sum().backward()
+    # device
+    c = ops.GRU if cell == 'gru' else ops.LSTM
+    emb_d = emb.to(dev).requires_grad_(True)
+    ws_d = [w.to(dev).requires_grad_(True) for w in ws]
+    _, res_idx = ops.sort_resort(lens.to(dev))
+    got = ops.encoder(c, ids.to(dev), lens.to(dev), mask.to(dev), res_idx, emb_d, ws_d)
+    assert rel(got, ref) < 2e-5
+    (got * dlast.to(dev)).sum().backward()
+    assert rel(emb_d.grad, P['Enc.Embedding.weight'].grad) < 1e-4
+    for d, suf in enumerate(['', '_reverse']):
+        for j, n in enumerate(names):
+            assert rel(ws_d[4 * d + j].grad, P['Enc.%s.%s%s' % (cn, n, suf)].grad) < 1e-4, (n, suf)
+    # eval mode (no mask, nothing saved)
+    with torch.no_grad():
+        got_e = ops.encoder(c, ids.to(dev), lens.to(dev), None, None, emb_d, ws_d)
+        ref_e = O.encoder(P, 'Enc.', cell, ids, lens, None)
+    assert rel(got_e, ref_e) < 2e-5
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+@pytest.mark.parametrize('shape', [(5, 8, 16, 16, 50), (32, 30, 200, 256, 1000)])
+def test_decoder_forward_backward(dev, cell, shape):
+    from cvae_amd import ops
+    B, T, E, Hd, V = shape
+    g = torch.Generator().manual_seed(3)
+    go = torch.randint(0, V, (B, T), generator=g)
+    emb = torch.randn(V, E, generator=g)
+    init = torch.randn(B, E, generator=g)
+    ws = _rnn_params(cell, 2 * E, Hd, False, 4)
+    k = 1.0 / math.sqrt(Hd)
+    W_c, b_c = (torch.rand(E, Hd, generator=g) * 2 - 1) * k, (torch.rand(E, generator=g) * 2 - 1) * k
+    m_in = (torch.rand(T, B, 2 * E, generator=g) > 0.2).float() / 0.8
+    m_out = (torch.rand(T, B, Hd, generator=g) > 0.2).float() / 0.8
+    dfinal = torch.randn(T, B, E, generator=g)
+    cn = 'GRU' if cell == 'gru' else 'LSTM'
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    P = {'D.Embedding.weight': emb.double().requires_grad_(True), 'D.W_c.weight': W_c.double().requires_grad_(True),
+         'D.W_c.bias': b_c.double().requires_grad_(True)}
+    for j, n in enumerate(names):
+        P['D.%s.%s' % (cn, n)] = ws[j].double().requires_grad_(True)
+    init64 = init.double().requires_grad_(True)
+    ref = O.decoder_final(P, 'D.', cell, init64, go, m_in.double(), m_out.double())
+    (ref * dfinal.double()).sum().backward()
+    c = ops.GRU if cell == 'gru' else ops.LSTM
+    emb_d = emb.to(dev).requires_grad_(True)
+    init_d = init.to(dev).requires_grad_(True)
+    w_d = [w.to(dev).requires_grad_(True) for w in ws + [W_c, b_c]]
+    got = ops.decoder(c, True, init_d, go.to(dev), m_in.to(dev), m_out.to(dev), emb_d, w_d)
+    assert rel(got, ref) < 2e-5
+    (got * dfinal.to(dev)).sum().backward()
+    assert rel(init_d.grad, init64.grad) < 1e-4
+    assert rel(emb_d.grad, P['D.Embedding.weight'].grad) < 1e-4
+    refs = [P['D.%s.%s' % (cn, n)].grad for n in names] + [P['D.W_c.weight'].grad, P['D.W_c.bias'].grad]
+    for a, b in zip(w_d, refs):
+        assert rel(a.grad, b) < 1e-4
+    # eval path with the de-duplicated input projection, R = n*B rows (small and > 256 rows)
+    for n_rep in (2, 60 if B == 5 else 10):
+        init_r = torch.randn(n_rep * B, E, generator=g)
+        with torch.no_grad():
+            ref_e = O.decoder_final(P, 'D.', cell, init_r.double(), go.repeat(n_rep, 1))
+            got_e = ops.decoder(c, False, init_r.to(dev), go.to(dev), None, None, emb_d, w_d)
+        assert rel(got_e, ref_e) < 2e-5, n_rep
+
+
+@pytest.mark.parametrize('shape', [(7, 5, 16, 50), (40, 32, 200, 10002), (3, 700, 200, 20001)])
+def test_projce_forward_backward(dev, shape):
+    from cvae_amd import ops
+    T, R, E, V = shape
+    g = torch.Generator().manual_seed(5)
+    final = torch.tanh(torch.randn(T, R, E, generator=g))
+    W = torch.randn(V, E, generator=g) * 0.1
+    b = torch.randn(V, generator=g) * 0.1
+    eos = torch.randint(0, V, (R, T), generator=g)
+    eos[:, -1] = 0
+    eos[0, :] = 0                                   # an all-pad sentence
+    eos[1, 0] = V - 1
+    gs = torch.randn(R, generator=g)
+    f64 = final.double().requires_grad_(True)
+    P = {'D.ToVocab.weight': W.double().requires_grad_(True), 'D.ToVocab.bias': b.double().requires_grad_(True)}
+    ref = O.seq_xent(P, 'D.', f64, eos)
+    (ref * gs.double()).sum().backward()
+    fd, Wd, bd = (t.to(dev).requires_grad_(True) for t in (final, W, b))
+    got = ops.proj_ce(fd, Wd, bd, eos.to(dev), 0)
+    assert rel(got, ref) < 2e-5
+    (got * gs.to(dev)).sum().backward()
+    assert rel(fd.grad, f64.grad) < 1e-4
+    assert rel(Wd.grad, P['D.ToVocab.weight'].grad) < 1e-4
+    assert rel(bd.grad, P['D.ToVocab.bias'].grad) < 1e-4
+    lg = ops.logits_bt(fd, Wd, bd)
+    assert rel(lg, O.decoder_logits(P, 'D.', f64)) < 2e-5
+
+
+def test_latent_kernels(dev):
+    from cvae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, Z, E = 33, 32, 200
+    mu, mu_p = torch.randn(B, Z, generator=g), torch.randn(B, Z, generator=g)
+    sg, sg_p = torch.rand(B, Z, generator=g) + 0.3, torch.rand(B, Z, generator=g) + 0.3
+    gk = torch.randn(B, generator=g)
+    for prior in (False, True):
+        a = [t.double().requires_grad_(True) for t in ((mu, sg, mu_p, sg_p) if prior else (mu, sg))]
+        ref = O.kl_pair(*a) if prior else O.kl_std(*a)
+        (ref * gk.double()).sum().backward()
+        d = [t.to(dev).requires_grad_(True) for t in ((mu, sg, mu_p, sg_p) if prior else (mu, sg))]
+        got = ops.kl_div(*d)
+        assert rel(got, ref) < 1e-5
+        (got * gk.to(dev)).sum().backward()
+        for x, y in zip(d, a):
+            assert rel(x.grad, y.grad) < 1e-5
+    init, init_c = torch.randn(B, E, generator=g) * 0.3, torch.randn(B, E, generator=g) * 0.3
+    for euclid in (False, True):
+        i64 = init.double().requires_grad_(True)
+        ref = O.couple_loss(i64, init_c.double(), Z, euclid)
+        (ref * gk.double()).sum().backward()
+        idv = init.to(dev).requires_grad_(True)
+        got = ops.couple_loss(idv, init_c.to(dev), Z, euclid)
+        assert rel(got, ref) < 1e-5
+        (got * gk.to(dev)).sum().backward()
+        assert rel(idv.grad, i64.grad) < 1e-5
+    eps = torch.randn(B, Z, generator=g)
+    m64, s64 = mu.double().requires_grad_(True), sg.double().requires_grad_(True)
+    ((m64 + s64 * eps.double()) ** 2).sum().backward()
+    md, sd = mu.to(dev).requires_grad_(True), sg.to(dev).requires_grad_(True)
+    z = ops.ReparamFn.apply(md, sd, eps.to(dev))
+    (z ** 2).sum().backward()
+    assert rel(md.grad, m64.grad) < 1e-5 and rel(sd.grad, s64.grad) < 1e-5
+
+
+def test_iw_reduce_and_mi(dev):
+    from cvae_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (K, B, Z) in ((10, 5, 4), (500, 32, 32), (100, 513, 32)):
+        mu, sg = torch.randn(B, Z, generator=g), torch.rand(B, Z, generator=g) + 0.3
+        mu_p, sg_p = torch.randn(B, Z, generator=g), torch.rand(B, Z, generator=g) + 0.3
+        eps = torch.randn(K, B, Z, generator=g)
+        z = mu + sg * eps
+        xent = torch.rand(K, B, generator=g) * 300
+        for prior in (False, True):
+            mp = mu_p.double() if prior else torch.zeros(B, Z).double()
+            sp = sg_p.double() if prior else torch.ones(B, Z).double()
+            lpz = O.normal_log_prob(z.double(), mp, sp).sum(2)
+            lqz = O.normal_log_prob(z.double(), mu.double(), sg.double()).sum(2)
+            nll = -(O.log_sum_exp(lpz - xent.double() - lqz, 0) - math.log(K))
+            kl = (lqz - lpz).mean(0)
+            xm, n2, k2 = ops.iw_reduce(z.to(dev), xent.to(dev), mu.to(dev), sg.to(dev),
+                                       mu_p.to(dev) if prior else None, sg_p.to(dev) if prior else None)
+            assert rel(n2, nll) < 1e-5 and rel(k2, kl) < 1e-4 and rel(xm, xent.double().mean(0)) < 1e-5
+        if K <= 100:
+            pair = O.normal_log_prob(z.double().unsqueeze(2), mu.double()[None, None], sg.double()[None, None]).sum(3)
+            pair = pair.masked_fill(torch.eye(B, dtype=torch.bool).unsqueeze(0), -float('inf'))
+            ref = O.normal_log_prob(z.double(), mu.double(), sg.double()).sum(2).mean(0) - \
+                (O.log_sum_exp(pair, 2) - math.log(B - 1)).mean(0)
+            got = ops.mi(z.to(dev), mu.to(dev), sg.to(dev))
+            assert float((got.double().cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
+
+
+def test_clip_adam_alias_semantics(dev):
+    """Flat clip + Adam vs the oracle's per-listing loop, 3 steps, both the
+    clipped and the un-clipped regime."""
+    from cvae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n_emb, n_rest = 5000, 12345
+    for scale in (0.01, 50.0):
+        p = torch.randn(n_emb + n_rest, generator=g)
+        P = {'A.Embedding.weight': p[:n_emb].clone(), 'rest': p[n_emb:].clone()}
+        P['B.Embedding.weight'] = P['C.Embedding.weight'] = P['A.Embedding.weight']
+        keys = ['A.Embedding.weight', 'rest', 'B.Embedding.weight', 'C.Embedding.weight']
+        state = {}
+        pd = p.to(dev)
+        m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+        sumsq, norm = torch.zeros(2, device=dev), torch.zeros(1, device=dev)
+        for step in range(3):
+            gr = torch.randn(n_emb + n_rest, generator=g) * scale
+            ge = gr[:n_emb].clone()
+            grads = {'A.Embedding.weight': ge, 'B.Embedding.weight': ge, 'C.Embedding.weight': ge,
+                     'rest': gr[n_emb:].clone()}
+            total = O.clip_and_adam(P, grads, state, keys)
+            gd = gr.to(dev)
+            ops.clip_adam(pd, gd, m, v, 0, n_emb, 3, 30.0, 1e-3, (0.9, 0.999), 1e-8, step, step * 3, sumsq, norm)
+            assert abs(float(norm) - total) < 1e-4 * total
+            ref = torch.cat([P['A.Embedding.weight'], P['rest']])
+            assert float((pd.cpu() - ref).abs().max()) < 2e-6, (scale, step)

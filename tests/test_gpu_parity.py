@@ -1,0 +1,297 @@
+"""End-to-end parity on the GPU against the golden vectors recorded from the reference
+(tests/golden) and against the CPU oracle at realistic shapes.
+
+Bars (BASELINE.json north_star): indices bit-exact; loss / NLL / KL / MI / PPL within 1e-4
+relative; gradients within 1e-3 relative (per tensor, relative to its largest entry)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import Golden, names   # noqa: E402
+from oracle import cvae_oracle as O     # noqa: E402  (checker only)
+
+LOSS_TOL, GRAD_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from cvae_amd import _lib
+    _lib.init(0)
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def close(a, b, tol):
+    return abs(float(a) - float(b)) <= tol * abs(float(b)) + 1e-7
+
+
+def make_trainer(g, dev, prefix='init/'):
+    from cvae_amd import harness
+    m = g.meta
+    hp = harness.HParams(model=m['model'], cell=m['cell'], V=m['V'], E=m['E'], H=m['H'], Z=m['Z'],
+                         dropout=m['dropout'], lr=m['lr'], clip_norm=m['clip_norm'],
+                         annealing_start=m['annealing_start'], annealing_step=m['annealing_step'],
+                         lambda_couple=m['lambda_couple'], lambda_seq_couple=m['lambda_seq_couple'],
+                         euclidean_dist=m['euclidean_dist'], max_len=m['max_len'], batch_size=m['B'])
+    model = harness.build_model(hp, 'cpu', seed=0)
+    model.load_state_dict({k: g.t(prefix + k) for k in m['state_keys']}, strict=True)
+    return harness.Trainer(hp, dev, model=model.to(dev))
+
+
+@pytest.mark.parametrize('name', names())
+def test_train_steps_match_reference(dev, name):
+    from cvae_amd import modules
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev)
+    sd = tr.model.state_dict(keep_vars=True)
+    try:
+        for it in range(m['n_train_steps']):
+            p = 'train/%d/' % it
+            batch = {k: v.to(dev) for k, v in g.batch(p).items()}
+            modules.set_noise_source(modules.ReplayNoise(g.group(p + 'noise/')))
+            res = tr.forward_backward(batch)
+            assert close(res['seq'], g.t(p + 'seq_per_sent').mean(), LOSS_TOL)
+            assert close(res['kl'], g.t(p + 'kl_elem').sum(1).mean(), LOSS_TOL)
+            if O.is_couple(m['model']):
+                assert close(res['seq_c'], g.t(p + 'seq_c_per_sent').mean(), LOSS_TOL)
+            assert close(res['tot'], g.np(p + 'tot'), LOSS_TOL)
+            for k in m['state_keys']:
+                if k in m['none_grad_keys']:
+                    assert float(sd[k].grad.abs().max()) == 0.0, k
+                else:
+                    assert rel(sd[k].grad, g.t(p + 'grad/' + k)) < GRAD_TOL, (it, k)
+            tr.opt.step()
+            for k in m['state_keys']:
+                if (p + 'post/' + k) in g:
+                    assert rel(sd[k], g.t(p + 'post/' + k)) < 2e-4, (it, k)
+    finally:
+        modules.set_noise_source(None)
+
+
+@pytest.mark.parametrize('name', [n for n in names() if n.endswith('tiny')])
+def test_forward_outputs_match_reference(dev, name):
+    """mu, sigma, init, init_couple and the materialised logits of the first train batch."""
+    from cvae_amd import modules
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev)
+    p = 'train/0/'
+    batch = {k: v.to(dev) for k, v in g.batch(p).items()}
+    modules.set_noise_source(modules.ReplayNoise(g.group(p + 'noise/')))
+    try:
+        tr.model.train(True)
+        with torch.no_grad():
+            if O.is_dialog(m['model']):
+                out = tr.model(post_bare=batch['post_bare'], post_len=batch['post_len'], resp_go=batch['resp_go'],
+                               resp_len=batch['resp_len'], resp_bare=batch['resp_bare'])
+                logits, prior, post = out[0], out[1], out[2]
+                assert rel(prior.loc, g.t(p + 'mu_prior')) < 1e-4 and rel(prior.scale, g.t(p + 'sigma_prior')) < 1e-4
+                extra = out[3:]
+            else:
+                out = tr.model(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
+                logits, post = out[0], out[1]
+                extra = out[4:]
+        assert rel(post.loc, g.t(p + 'mu')) < 1e-4 and rel(post.scale, g.t(p + 'sigma')) < 1e-4
+        assert tuple(logits.shape) == tuple(g.np(p + 'logits').shape)
+        assert rel(logits.materialize(), g.t(p + 'logits')) < 1e-4
+        if O.is_couple(m['model']):
+            logits_c, init, init_c = extra
+            assert rel(logits_c.materialize(), g.t(p + 'logits_couple')) < 1e-4
+            assert rel(init, g.t(p + 'init')) < 1e-4 and rel(init_c, g.t(p + 'init_couple')) < 1e-4
+    finally:
+        modules.set_noise_source(None)
+
+
+def _chunks(eps):
+    return [eps[i:i + 2] for i in range(0, eps.shape[0], 2)]
+
+
+@pytest.mark.parametrize('name', names())
+def test_iw_nll_matches_reference(dev, name):
+    from cvae_amd import modules
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    try:
+        for K in (2, 10):
+            p = 'iw/K%d/' % K
+            b = {k: v.to(dev) for k, v in g.batch(p).items()}
+            modules.set_noise_source(modules.ReplayNoise({'iw_eps': _chunks(g.t(p + 'eps'))}))
+            if O.is_dialog(m['model']):
+                xent, nll, kl = tr.model.test_lm(post_bare=b['post_bare'], post_len=b['post_len'], resp_go=b['resp_go'],
+                                                 resp_len=b['resp_len'], resp_bare=b['resp_bare'],
+                                                 resp_eos=b['resp_eos'], n_sample=K)
+            else:
+                xent, nll, kl, z = tr.model.test_lm(bare=b['bare'], sent_len=b['len'], go=b['go'], eos=b['eos'],
+                                                    n_sample=K)
+                assert rel(z, g.t(p + 'z')) < LOSS_TOL
+            assert rel(xent, g.t(p + 'xent')) < LOSS_TOL
+            assert rel(nll, g.t(p + 'nll')) < LOSS_TOL
+            assert rel(kl, g.t(p + 'kl')) < 5e-4       # kl = mean_k(log q - log p): cancellation, abs err ~1e-6
+    finally:
+        modules.set_noise_source(None)
+
+
+@pytest.mark.parametrize('name', names())
+def test_corpus_metrics_match_reference(dev, name):
+    """a1 + a13 + a16: raw ids -> device batches -> IW-NLL -> nll / xent / kl / ppl."""
+    from cvae_amd import modules, data, harness
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev, 'eval/')
+
+    def corpus(prefix):
+        flat, off = g.np(prefix + 'raw_flat'), g.np(prefix + 'raw_offsets')
+        return data.Corpus([flat[off[i]:off[i + 1]] for i in range(len(off) - 1)], m['max_len'])
+
+    B = m['B']
+    eps = [c for b in range(m['corpus_batches']) for c in _chunks(g.t('corpus/eps/%d' % b))]
+    modules.set_noise_source(modules.ReplayNoise({'iw_eps': eps}))
+    try:
+        if O.is_dialog(m['model']):
+            posts, resps = corpus('corpus/post_'), corpus('corpus/resp_')
+            n = len(resps)
+            batches = (harness.dialog_batch(posts, resps, range(i, min(n, i + B)), dev) for i in range(0, n, B))
+        else:
+            c = corpus('corpus/')
+            n = len(c)
+            batches = (harness.text_batch(c, range(i, min(n, i + B)), dev, truncate=False) for i in range(0, n, B))
+        got, _ = tr.iw_eval(batches, m['corpus_K'])
+    finally:
+        modules.set_noise_source(None)
+    for k in ('nll', 'xent', 'ppl'):
+        assert close(got[k], g.np('corpus/' + k), LOSS_TOL), k
+    assert close(got['kl'], g.np('corpus/kl'), 5e-4)
+
+
+@pytest.mark.parametrize('name', names('text_'))
+def test_mi_matches_reference(dev, name):
+    from cvae_amd import modules
+    g = Golden(name)
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    bare, go, ln = g.t('mi/bare').to(dev), g.t('mi/go').to(dev), g.t('mi/len').to(dev)
+    try:
+        for Bm in (5, bare.shape[0]):
+            modules.set_noise_source(modules.ReplayNoise({'mi_eps': _chunks(g.t('mi/B%d/eps' % Bm))}))
+            mi, _ = tr.model.estimate_mi(go=go[:Bm], sent_len=ln[:Bm], bare=bare[:Bm].contiguous(), n_sample=4)
+            ref = g.t('mi/B%d/mi' % Bm)
+            assert float((mi.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 2e-5
+        modules.set_noise_source(modules.ReplayNoise({'mi_eps': _chunks(g.t('mi/eps'))}))
+        avg = tr.estimate_mi([dict(go=go, len=ln, bare=bare)], n_sample=100)
+        assert abs(avg - float(g.np('mi/avg'))) < 1e-4 * abs(float(g.np('mi/avg'))) + 2e-5
+    finally:
+        modules.set_noise_source(None)
+
+
+# ----------------------------------------------------------------------------- realistic shapes
+@pytest.mark.parametrize('model,cell,shape', [
+    ('vae-couple', 'gru', 'ptb'), ('vae-couple', 'lstm', 'ptb'), ('cvae-couple', 'gru', 'switchboard'),
+    ('vae', 'lstm', 'ptb'),
+])
+def test_train_step_vs_oracle_full_shape(dev, model, cell, shape):
+    """PTB / Switchboard shapes (V=10k, E=200, H=128, B=32): losses and every gradient vs
+    the oracle (fp32 CPU) with the same weights, batch and noise; V shrunk to 2000 so the
+    CPU oracle stays in seconds."""
+    from cvae_amd import modules, data, harness
+    s = dict(data.SHAPES[shape])
+    s['V'] = 2000
+    hp = harness.HParams(model=model, cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'],
+                         lambda_couple=2.0 if model.startswith('cvae') else 0.1)
+    tr = harness.Trainer(hp, dev, seed=3)
+    sd = tr.model.state_dict(keep_vars=True)
+    P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in sd.items()})
+    keys = list(sd.keys())
+    B = 32
+    sents = data.synthetic_sentences(2 * B, s['V'], s['mu'], s['sigma'], 40, seed=5)
+    c1, c2 = data.Corpus(sents[:B]), data.Corpus(sents[B:])
+    if hp.is_dialog():
+        batch = harness.dialog_batch(c1, c2, range(B), dev)
+    else:
+        batch = harness.text_batch(c1, range(B), dev)
+    cb = {k: v.cpu() for k, v in batch.items()}
+    # a1 cross-check against the oracle's layout
+    if not hp.is_dialog():
+        ob = O.make_batch([x.tolist() for x in sents[:B]], 200, truncate=True)
+        for k, v in zip(('bare', 'go', 'eos', 'len'), ob):
+            assert np.array_equal(cb[k].numpy(), v)
+    gen = torch.Generator().manual_seed(9)
+    T = (cb['resp_go'] if hp.is_dialog() else cb['go']).shape[1]
+    E, Hd, Z = s['E'], 2 * s['H'], s['Z']
+
+    def drop(*shape_):
+        return (torch.rand(*shape_, generator=gen) > 0.2).float() / 0.8
+
+    noise = {'eps': torch.randn(B, Z, generator=gen), 'dec_in_drop': drop(T, B, 2 * E), 'dec_out_drop': drop(T, B, Hd)}
+    if hp.is_couple():
+        noise.update(decc_in_drop=drop(T, B, 2 * E), decc_out_drop=drop(T, B, Hd))
+    if hp.is_dialog():
+        noise.update(post_enc_drop=drop(cb['post_bare'].shape[1], B, E), resp_enc_drop=drop(cb['resp_bare'].shape[1], B, E))
+    else:
+        noise['enc_drop'] = drop(cb['bare'].shape[1], B, E)
+    replay = {k: (v.unsqueeze(0) if k == 'eps' else v) for k, v in noise.items()}
+    cfg = dict(latent_dim=Z, lambda_kl=0.37, lambda_couple=hp.lambda_couple, lambda_seq_couple=1.0,
+               euclidean_dist=False)
+    tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1     # lambda_KL = 0.37 at the next iter
+    modules.set_noise_source(modules.ReplayNoise(replay))
+    try:
+        res = tr.forward_backward(batch)
+    finally:
+        modules.set_noise_source(None)
+    assert abs(res['lambda_kl'] - 0.37) < 1e-9
+    for p_ in {id(v): v for v in P.values()}.values():
+        p_.requires_grad_(True)
+    out = O.train_forward(P, model, cell, cb, noise, cfg)
+    out['tot'].backward()
+    for k in ('seq', 'kl', 'seq_c', 'couple', 'tot'):
+        if k in out:
+            assert close(res[k], out[k].detach(), LOSS_TOL), k
+    for k in keys:
+        if P[k].grad is None:
+            assert float(sd[k].grad.abs().max()) == 0.0, k
+        else:
+            assert rel(sd[k].grad, P[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+def test_iw_nll_vs_oracle_and_row_chunking(dev, cell):
+    """K=20 at PTB shape vs the oracle; and the same estimate with a different rows-per-pass
+    split (size-independent property: per-row results do not depend on the chunking)."""
+    from cvae_amd import modules, data, harness, settings
+    s = dict(data.SHAPES['ptb'])
+    s['V'] = 3000
+    hp = harness.HParams(model='vae-couple', cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'])
+    tr = harness.Trainer(hp, dev, seed=4)
+    B, K = 16, 20
+    c = data.Corpus(data.synthetic_sentences(B, s['V'], s['mu'], s['sigma'], 30, seed=6))
+    batch = harness.text_batch(c, range(B), dev, truncate=False)
+    eps = torch.randn(K, B, s['Z'], generator=torch.Generator().manual_seed(2))
+    P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    cb = {k: v.cpu() for k, v in batch.items()}
+    m = int(cb['len'].max())
+    cb_t = dict(bare=cb['bare'][:, :m], go=cb['go'][:, :m + 1], eos=cb['eos'][:, :m + 1], len=cb['len'])
+    with torch.no_grad():
+        xent, nll, kl, _ = O.iw_nll(P, 'vae-couple', cell, cb_t, eps)
+    tr.model.train(False)
+    outs = []
+    try:
+        for rows in (16384, 5 * B):
+            settings.iw_max_rows = rows
+            modules.set_noise_source(modules.ReplayNoise({'iw_eps': _chunks(eps)}))
+            outs.append(tr.model.test_lm(bare=batch['bare'], sent_len=batch['len'], go=batch['go'], eos=batch['eos'],
+                                         n_sample=K))
+    finally:
+        settings.iw_max_rows = 16384
+        modules.set_noise_source(None)
+    assert rel(outs[0][0], xent) < LOSS_TOL and rel(outs[0][1], nll) < LOSS_TOL and rel(outs[0][2], kl) < 5e-4
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert rel(a, b) < 1e-6
