@@ -42,6 +42,8 @@ class ReplayNoise(NoiseSource):
         if name not in self.table or not self.table[name]:
             return None
         t = self.table[name].pop(0).to(device=device, dtype=torch.float32).contiguous()
+        if t.dim() == len(shape) - 1 and shape[0] == 1:      # a (1,B,Z) draw recorded as (B,Z)
+            t = t.unsqueeze(0)
         assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
         return t
 

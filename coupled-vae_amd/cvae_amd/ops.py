@@ -54,8 +54,10 @@ def gemm(A, B, transA=False, transB=False, bias=None, act=ACT_NONE, out=None, be
     N = B.shape[0] if transB else B.shape[1]
     if out is None:
         out = _f((M, N), A)
-    call('cvae_gemm', int(transA), int(transB), M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out),
-         out.stride(0), ptr(bias), act, beta, stream())
+    for t in (A, B, out):      # row-strided views are fine: the ABI takes leading dimensions
+        assert t.dim() == 2 and t.stride(1) == 1
+    call('cvae_gemm', int(transA), int(transB), M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0),
+         out.data_ptr(), out.stride(0), ptr(bias), act, beta, stream())
     return out
 
 

@@ -29,6 +29,8 @@ def rel(a, b):
 
 
 def close(a, b, tol):
+    a = a.detach() if torch.is_tensor(a) else a
+    b = b.detach() if torch.is_tensor(b) else b
     return abs(float(a) - float(b)) <= tol * abs(float(b)) + 1e-7
 
 
