@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- Coupled-VAE hot path on MI355X: train tokens/s + IW-NLL sentences/s.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload at N=1 (BASELINE.json configs[1]): Yelp-shape Coupled-VAE (V=20000, E=200, H=256,
+Z=32, IMQ coupling), batch 32, synthetic corpus (lengths lognormal(4.4,0.5) capped at 200),
+LSTM cells (the cell BASELINE's metric names; --cell gru for the reference default).
+A "step" = one training step (forward, backward, clip, Adam) on one batch of 32 sentences.
+After the K timed steps the IW-NLL evaluation (n_sample=500) of --iw-batches batches is
+timed separately.  `value` = training tokens/s of the whole job (a token = one non-pad
+target = len+1 per sentence, the PPL denominator), `iw_nll.value` = sentences/s.
+N > 1: one process per GPU, batch 32 PER GPU (weak scaling), gradients all-reduced over
+RCCL before the clip; evaluation batches sharded over ranks, one final all-reduce.
+
+Inputs are resident in HBM before the timed regions.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'coupled-vae_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, dense fp32 matrix
+PEAK_HBM_GBS = 8000.0
+KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
+           3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_fwd_kernel', 'mfma')}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='yelp', choices=['ptb', 'yelp', 'yahoo'])
+    ap.add_argument('--cell', default='lstm', choices=['gru', 'lstm'])
+    ap.add_argument('--iw-samples', type=int, default=500)
+    ap.add_argument('--iw-batches', type=int, default=2, help='evaluation batches per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-iw', action='store_true')
+    return ap.parse_args()
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def profile_read(lib):
+    out = {}
+    for k, (name, bound) in KERNELS.items():
+        n, ms, work = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+        rc = lib.cvae_profile_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
+        assert rc == 0
+        out[name] = dict(launches=n.value, ms=ms.value, work=work.value, bound=bound)
+    return out
+
+
+def roofline_of(prof):
+    """The kernel with the largest total time in the profiled pass."""
+    name, rec = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    if rec['launches'] == 0 or rec['ms'] == 0:
+        return None
+    per_s = rec['work'] / (rec['ms'] * 1e-3)
+    if rec['bound'] == 'mfma':
+        ach, peak, unit = per_s / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
+    else:
+        ach, peak, unit = per_s / 1e9, PEAK_HBM_GBS, 'GB/s'
+    return dict(kernel=name, bound=rec['bound'], achieved=round(ach, 3), peak=peak, unit=unit,
+                frac=round(ach / peak, 4), traffic=None, launches=rec['launches'],
+                avg_launch_ms=round(rec['ms'] / rec['launches'], 5),
+                work_per_launch=rec['work'] / rec['launches'])
+
+
+def cpu_baseline(args, shape):
+    """The oracle ("port": CPU restatement proven equal to the reference, tests/test_oracle_golden.py)
+    timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import cvae_oracle as O
+    n_thr = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(n_thr)
+    model, cell = 'vae-couple', args.cell
+    P = O.tie_aliases(O.init_params(model, cell, shape['V'], shape['E'], shape['H'], shape['Z'], seed=0))
+    B = 32
+    sents = O.synthetic_sentences(B, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=0)
+    bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch(sents, 200, truncate=True))
+    batch = dict(bare=bare, go=go, eos=eos, len=ln)
+    L, T = bare.shape[1], go.shape[1]
+    g = torch.Generator().manual_seed(0)
+
+    def drop(*s):
+        return (torch.rand(*s, generator=g) > 0.2).float() / 0.8
+
+    Hd, E = 2 * shape['H'], shape['E']
+    noise = dict(enc_drop=drop(L, B, E), eps=torch.randn(B, shape['Z'], generator=g),
+                 dec_in_drop=drop(T, B, 2 * E), dec_out_drop=drop(T, B, Hd),
+                 decc_in_drop=drop(T, B, 2 * E), decc_out_drop=drop(T, B, Hd))
+    cfg = dict(latent_dim=shape['Z'], lambda_kl=0.5, lambda_couple=0.1, lambda_seq_couple=1.0, euclidean_dist=False)
+    keys = [k for k in P.keys() if not k.startswith('BoW') and 'PosteriorGaussianCouple.toSigma' not in k]
+    state = {}
+    O.train_step(P, model, cell, batch, noise, cfg, state, keys)          # warm-up
+    n_steps = 2
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        O.train_step(P, model, cell, batch, noise, cfg, state, keys)
+    dt = (time.perf_counter() - t0) / n_steps
+    tokens = int((ln + 1).sum())
+    # IW-NLL sample: 4 sentences x 10 samples, scaled to sentences/s at the configured K
+    Bs, Ks = 4, 10
+    sb = dict(bare=bare[:Bs], go=go[:Bs], eos=eos[:Bs], len=ln[:Bs])
+    m = int(ln[:Bs].max())
+    sb = dict(bare=sb['bare'][:, :m], go=sb['go'][:, :m + 1], eos=sb['eos'][:, :m + 1], len=sb['len'])
+    eps = torch.randn(Ks, Bs, shape['Z'], generator=g)
+    for pp in {id(v): v for v in P.values()}.values():
+        pp.requires_grad_(False)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.iw_nll(P, model, cell, sb, eps)
+    dt_iw = time.perf_counter() - t0
+    sent_per_s = Bs / (dt_iw * args.iw_samples / Ks)
+    return dict(value=round(tokens / dt, 1), unit='tokens/s', cores=n_thr, kind='port',
+                sample='%d train steps (batch 32, same shape, after 1 warm-up) of the CPU oracle; IW-NLL: %d sentences x '
+                       '%d samples, linearly scaled to K=%d' % (n_steps, Bs, Ks, args.iw_samples),
+                iw_nll_sentences_per_s=round(sent_per_s, 4), ms_per_step=round(dt * 1e3, 1))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from cvae_amd import _lib, data, harness
+    _lib.init(local_rank)
+
+    shape = data.SHAPES[args.workload]
+    hp = harness.HParams(model='vae-couple', cell=args.cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'],
+                         annealing_start=1000 if args.workload != 'ptb' else 2000,
+                         euclidean_dist=(args.workload == 'yahoo'))
+    tr = harness.Trainer(hp, dev, seed=0)          # same seed: identical initial weights on every rank
+    tr.iter_num = 20000                            # mid-annealing: lambda_KL > 0, every loss term live
+    B = hp.batch_size
+    n_batches = max(args.steps + args.warmup, 1)
+    sents = data.synthetic_sentences(B * n_batches, shape['V'], shape['mu'], shape['sigma'], shape['cap'],
+                                     seed=1000 + rank)
+    corpus = data.Corpus(sents)
+    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev) for i in range(n_batches)]
+    tokens = [corpus.n_tokens(range(i * B, (i + 1) * B)) for i in range(n_batches)]
+    torch.manual_seed(1234 + rank)                 # dropout / eps streams differ per rank
+
+    for i in range(args.warmup):
+        tr.train_step(batches[i])
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        tr.train_step(batches[i])
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    tok = torch.tensor([float(sum(tokens[args.warmup:args.warmup + args.steps]))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tok)
+    train_tok_s = float(tok.item()) / dt
+
+    # ---- IW-NLL evaluation (test.py path): sentences sharded over ranks
+    iw = None
+    if not args.no_iw:
+        ev = data.Corpus(data.synthetic_sentences(B * (args.iw_batches + 1), shape['V'], shape['mu'], shape['sigma'],
+                                                  shape['cap'], seed=5000 + rank))
+        ebatches = [harness.text_batch(ev, range(i * B, (i + 1) * B), dev, truncate=False)
+                    for i in range(args.iw_batches + 1)]
+        tr.iw_eval(ebatches[:1], args.iw_samples)                       # warm-up
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        metrics, _ = tr.iw_eval(ebatches[1:], args.iw_samples)
+        barrier_sync(world)
+        dt_iw = max_over_ranks(time.perf_counter() - t0, world, dev)
+        iw = dict(value=round(metrics['n'] / dt_iw, 3), unit='sentences/s', n_sample=args.iw_samples,
+                  sentences=metrics['n'], seconds=round(dt_iw, 4))
+
+    # ---- roofline leg: same work once more with the library's per-kernel HIP events on
+    roof = None
+    if rank == 0:
+        _lib.call('cvae_profile_enable', 1)
+        for i in range(min(3, n_batches)):
+            tr.train_step(batches[i])
+        if not args.no_iw:
+            tr.iw_eval(ebatches[1:2], args.iw_samples)
+        torch.cuda.synchronize()
+        prof = profile_read(_lib.lib)
+        _lib.call('cvae_profile_enable', 0)
+        roof = roofline_of(prof)
+        roof_all = {k: dict(launches=v['launches'], ms=round(v['ms'], 3),
+                            rate=round(v['work'] / max(v['ms'], 1e-9) / (1e9 if v['bound'] == 'mfma' else 1e6), 2),
+                            unit='TFLOP/s' if v['bound'] == 'mfma' else 'GB/s') for k, v in prof.items()}
+    barrier_sync(world)
+
+    if rank == 0:
+        out = {
+            'metric': 'train tokens/s (Coupled-VAE train step) + IW-NLL eval sentences/s (field iw_nll)',
+            'value': round(train_tok_s, 1), 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s-shape Coupled-VAE (vae-couple, %s): V=%d E=%d H=%d Z=%d, batch %d per GPU, '
+                                   'lengths lognormal(%.1f,%.2f) cap %d; train step + IW-NLL K=%d'
+                                   % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
+                                      shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
+                       'parallelism': 'dp%d' % world},
+            'iw_nll': iw, 'roofline': roof, 'kernels': roof_all,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, shape)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

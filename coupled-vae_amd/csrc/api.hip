@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.hpp"
 #include "misc.hpp"
 
@@ -23,6 +25,37 @@ int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   set_error("%s: %s", what, hipGetErrorString(e));
   return -2;
+}
+
+// ---------------------------------------------------------------- profiling state
+struct ProfRec { int kernel; double work; hipEvent_t beg, end; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static size_t g_pool_used = 0;
+constexpr size_t kProfMaxRecs = 1 << 17;
+
+static bool prof_event(hipEvent_t* e) {
+  if (g_pool_used == g_pool.size()) {
+    hipEvent_t ne;
+    if (hipEventCreate(&ne) != hipSuccess) return false;
+    g_pool.push_back(ne);
+  }
+  *e = g_pool[g_pool_used++];
+  return true;
+}
+
+ProfScope::ProfScope(int kernel, hipStream_t stream, double work) : slot(-1), s(stream) {
+  if (!g_prof_on || g_prof.size() >= kProfMaxRecs) return;
+  ProfRec r;
+  r.kernel = kernel; r.work = work;
+  if (!prof_event(&r.beg) || !prof_event(&r.end)) return;
+  (void)hipEventRecord(r.beg, s);
+  slot = (int)g_prof.size();
+  g_prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].end, s);
 }
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -78,6 +111,26 @@ int cvae_init(int device) {
                "cvae_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                prop.gcnArchName);
   CVAE_TRY(check_hip(hipSetDevice(device), "hipSetDevice"));
+  return 0;
+}
+
+int cvae_profile_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof.clear();
+  g_pool_used = 0;
+  return 0;
+}
+
+int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_work) {
+  CVAE_REQUIRE(kernel >= 0 && kernel < PK_COUNT && launches && total_ms && total_work, "profile_read: bad argument");
+  *launches = 0; *total_ms = 0.0; *total_work = 0.0;
+  for (const ProfRec& r : g_prof) {
+    if (r.kernel != kernel) continue;
+    CVAE_TRY(check_hip(hipEventSynchronize(r.end), "profile_read: hipEventSynchronize"));
+    float ms = 0.f;
+    CVAE_TRY(check_hip(hipEventElapsedTime(&ms, r.beg, r.end), "profile_read: hipEventElapsedTime"));
+    *launches += 1; *total_ms += ms; *total_work += r.work;
+  }
   return 0;
 }
 

@@ -31,6 +31,16 @@ int check_hip(hipError_t e, const char* what);
     if (_rc) return _rc;        \
   } while (0)
 
+// ---- opt-in per-kernel timing (bench.py's roofline leg): HIP events recorded on the launch
+// stream around the kernels named below.  Off by default: no events, no overhead.
+enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_COUNT = 5 };
+struct ProfScope {
+  int slot;
+  hipStream_t s;
+  ProfScope(int kernel, hipStream_t stream, double work);   // work: algorithmic FLOPs (MFMA kernels) or bytes
+  ~ProfScope();
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -142,6 +142,7 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
     }
   }
   dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), ksplit);
+  ProfScope prof(PK_GEMM_TILED, s, 2.0 * d.M * d.N * d.K);
   if (!d.transA && d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a);
   else if (!d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a);
   else if (d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a);

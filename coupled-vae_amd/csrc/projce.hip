@@ -187,7 +187,10 @@ int launch_projce_forward(const float* X, const float* W, const float* bias, con
   a.vecW = aligned16(W) && (E % 4 == 0);
   // targets outside [0,V) never match a column: give them a defined logit
   CVAE_TRY(check_hip(hipMemsetAsync(a.tgt_logit, 0, (size_t)N * 4, s), "projce tgt memset"));
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nsplit, cdiv(N, CE_BM)), dim3(256), 0, s, a);
+  {
+    ProfScope prof(PK_CE_FWD, s, 2.0 * N * E * V);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nsplit, cdiv(N, CE_BM)), dim3(256), 0, s, a);
+  }
   CVAE_LAUNCH_CHECK("ce_fwd_kernel");
   hipLaunchKernelGGL(ce_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, 2 * nsplit, a.pm, a.ps,
                      a.tgt_logit, tgt, pad, loss, lse);

@@ -104,6 +104,8 @@ int launch_rnn_forward(const RnnFwd& a, hipStream_t s) {
       d.A = hprev; d.lda = a.H; d.B = a.W_hh; d.ldb = a.H; d.C = a.hp_scratch; d.ldc = (long)G * a.H;
       CVAE_TRY(launch_gemm(d, s));
       const int grid = cdiv(RH, 256);
+      // algorithmic bytes: hp + x-side (G each) + h_prev in, h out (+ c in/out for LSTM)
+      ProfScope prof(PK_CELL_FWD, s, 4.0 * RH * (2 * G + 2 + (a.cell == CELL_LSTM ? 2 : 0)));
       if (a.cell == CELL_GRU)
         hipLaunchKernelGGL((cell_fwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, xp,
                            a.xmod, a.xadd, a.b_hh, hprev, cprev, hout, cout, gates, a.lengths, t);
@@ -198,6 +200,8 @@ int launch_rnn_backward(const RnnBwd& a, hipStream_t s) {
     const int grid = cdiv(RH, 256);
     const float* dhs_t = a.dhs ? a.dhs + (long)t * RH : nullptr;
     const float* gates = a.gates + (long)t * a.R * 4 * a.H;
+    {
+    ProfScope prof(PK_CELL_BWD, s, 4.0 * RH * (4 + 2 * G + 4));
     if (a.cell == CELL_GRU)
       hipLaunchKernelGGL((cell_bwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, dhb[cur], nullptr, dhs_t,
                          gates, a.hs + in_slot * RH, nullptr, nullptr, a.dgx + goff, a.dgh + goff, dhb[cur ^ 1],
@@ -206,6 +210,7 @@ int launch_rnn_backward(const RnnBwd& a, hipStream_t s) {
       hipLaunchKernelGGL((cell_bwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, dhb[cur], dcb[cur], dhs_t,
                          gates, a.hs + in_slot * RH, a.cs + in_slot * RH, a.cs + out_slot * RH, a.dgx + goff,
                          a.dgh ? a.dgh + goff : nullptr, dhb[cur ^ 1], dcb[cur ^ 1], a.lengths, t);
+    }
     CVAE_LAUNCH_CHECK("cell_bwd_kernel");
     // dh_{t-1} += dG_h[t] . W_hh      (R x GH) . (GH x H)
     if (a.R <= SKINNY_MAX_ROWS) {

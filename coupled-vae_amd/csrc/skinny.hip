@@ -175,6 +175,7 @@ int launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
   if (nw < 1) nw = 1;
   const size_t lds = (size_t)nw * mt * ng * 256 * sizeof(float);
   dim3 grid(cdiv(a.N, 16), cdiv(a.M, 16 * mt));
+  ProfScope prof(PK_SKINNY, s, 2.0 * a.M * a.N * a.K * ng);
   const int vecA = aligned16(a.A) && (a.lda % 4 == 0);
   const int vecB = a.transB && aligned16(a.B) && (a.ldb % 4 == 0);
   if (mt == 1) return launch_mt<1>(a, epi, nw, grid, lds, vecA, vecB, s);

@@ -50,6 +50,8 @@ SIGNATURES = {
     'cvae_iw_reduce': [P, P, P, P, P, P, I, I, I, P, P, P, P],
     'cvae_mi': [P, P, P, I, I, I, P, P, P],
     'cvae_clip_adam': [P, P, P, P, L, L, L, I, F, F, F, F, F, L, L, P, P, P],
+    'cvae_profile_enable': [I],
+    'cvae_profile_read': [I, P, P, P],
     'cvae_sum_time': [P, I, I, P, P],
     'cvae_axpy': [P, F, L, P, P],
 }

@@ -166,6 +166,14 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
                    float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
                    void* stream);
 
+/* ---- measurement aid, no reference counterpart: opt-in HIP-event timing of the library's
+ * own kernels on the launch stream (bench.py's roofline leg).  enable(1) resets and starts
+ * recording (creates events on first use), enable(0) stops.  kernel: 0 tiled MFMA GEMM,
+ * 1 skinny MFMA product / fused RNN step, 2 RNN cell forward, 3 RNN cell backward,
+ * 4 projection+CE forward.  total_work: algorithmic FLOPs (0,1,4) or bytes (2,3). */
+int cvae_profile_enable(int on);
+int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_work);
+
 /* small helpers used by the host mirror */
 int cvae_sum_time(const float* x, int T, int R, float* out, void* stream);       /* out[r] = sum_t x[t,r] */
 int cvae_axpy(const float* x, float a, int64_t n, float* y, void* stream);       /* y += a*x */
