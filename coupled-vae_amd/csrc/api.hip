@@ -188,19 +188,21 @@ int cvae_encoder_forward(int cell, int B, int L, int E, int H, int64_t V, const 
   CVAE_REQUIRE(cell == CELL_GRU || cs, "encoder_forward: LSTM needs cs");
   const int G = gates_of(cell);
   CVAE_TRY(launch_embed(L, B, E, 0, 0, ids, B, emb, nullptr, mask, mask_rows, X, s));
+  RnnFwd f[2] = {};
   for (int d = 0; d < 2; ++d) {
     const float* W_ih = w[4 * d + 0]; const float* W_hh = w[4 * d + 1];
     const float* b_ih = w[4 * d + 2]; const float* b_hh = w[4 * d + 3];
     float* xp = xproj + (long)d * L * B * G * H;
     CVAE_TRY(linear_nt(X, W_ih, E, b_ih, ACT_NONE, L * B, G * H, E, xp, s));
-    RnnFwd f = {};
-    f.cell = cell; f.T = L; f.R = B; f.H = H; f.reverse = d;
-    f.xproj = xp; f.xmod = B; f.W_hh = W_hh; f.b_hh = b_hh; f.lengths = len;
-    f.hs = hs + (long)d * (L + 1) * B * H;
-    f.cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
-    f.gates = gates ? gates + (long)d * L * B * 4 * H : nullptr;
-    CVAE_TRY(launch_rnn_forward(f, s));
-    const float* fin = f.hs + (long)(d ? 0 : L) * B * H;
+    f[d].cell = cell; f[d].T = L; f[d].R = B; f[d].H = H; f[d].reverse = d;
+    f[d].xproj = xp; f[d].xmod = B; f[d].W_hh = W_hh; f[d].b_hh = b_hh; f[d].lengths = len;
+    f[d].hs = hs + (long)d * (L + 1) * B * H;
+    f[d].cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
+    f[d].gates = gates ? gates + (long)d * L * B * 4 * H : nullptr;
+  }
+  CVAE_TRY(launch_rnn_forward_multi(f, 2, s));       // both directions advance in the same launches
+  for (int d = 0; d < 2; ++d) {
+    const float* fin = f[d].hs + (long)(d ? 0 : L) * B * H;
     CVAE_TRY(launch_copy_cols(B, H, fin, H, 0, last, 2L * H, d * H, s));
   }
   return 0;
@@ -208,8 +210,8 @@ int cvae_encoder_forward(int cell, int B, int L, int E, int H, int64_t V, const 
 
 int64_t cvae_encoder_backward_scratch(int cell, int B, int L, int E, int H) {
   const int64_t G = gates_of(cell);
-  //   dgx, dgh [L,B,G*H] + dX [L,B,E] + dh_last, dh0, dh_tmp, dc0, dc_tmp [B,H]
-  return 2 * (int64_t)L * B * G * H + (int64_t)L * B * E + 5 * (int64_t)B * H;
+  //   per direction: dgx, dgh [L,B,G*H], dh_last, dh0, dh_tmp, dc0, dc_tmp [B,H], W_hh^T [H,G*H]; shared dX [L,B,E]
+  return 2 * (2 * (int64_t)L * B * G * H + 5 * (int64_t)B * H + G * (int64_t)H * H) + (int64_t)L * B * E;
 }
 
 int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
@@ -222,36 +224,76 @@ int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const
   CVAE_REQUIRE(ids && len && w && X && hs && gates && dlast && dw && demb && scratch, "encoder_backward: null operand");
   const int G = gates_of(cell);
   const long LBG = (long)L * B * G * H, BH = (long)B * H;
-  float* dgx = scratch;
-  float* dgh = dgx + LBG;
-  float* dX = dgh + LBG;
-  float* dh_last = dX + (long)L * B * E;
-  float* dh0 = dh_last + BH; float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+  const long per_dir = 2 * LBG + 5 * BH + (long)G * H * H;
+  float* dX = scratch + 2 * per_dir;
+  RnnBwd r[2] = {};
+  float* dgx[2]; float* dgh[2];
   for (int d = 0; d < 2; ++d) {
-    const float* W_ih = w[4 * d + 0]; const float* W_hh = w[4 * d + 1];
+    float* base = scratch + d * per_dir;
+    dgx[d] = base; dgh[d] = base + LBG;
+    float* dh_last = base + 2 * LBG;
+    float* dh0 = dh_last + BH; float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+    float* whhT = dc_tmp + BH;
     CVAE_TRY(launch_copy_cols(B, H, dlast, 2L * H, d * H, dh_last, H, 0, s));
-    const float* hs_d = hs + (long)d * (L + 1) * B * H;
-    RnnBwd r = {};
-    r.cell = cell; r.T = L; r.R = B; r.H = H; r.reverse = d;
-    r.dh_last = dh_last; r.hs = hs_d; r.cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
-    r.gates = gates + (long)d * L * B * 4 * H; r.W_hh = W_hh; r.lengths = len;
-    r.dgx = dgx; r.dgh = (cell == CELL_GRU) ? dgh : nullptr;
-    r.dh0 = dh0; r.dc0 = dc0; r.dh_tmp = dh_tmp; r.dc_tmp = dc_tmp;
-    CVAE_TRY(launch_rnn_backward(r, s));
-    const float* dgh_eff = (cell == CELL_GRU) ? dgh : dgx;
+    r[d].cell = cell; r[d].T = L; r[d].R = B; r[d].H = H; r[d].reverse = d;
+    r[d].dh_last = dh_last; r[d].hs = hs + (long)d * (L + 1) * B * H;
+    r[d].cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
+    r[d].gates = gates + (long)d * L * B * 4 * H; r[d].W_hh = w[4 * d + 1]; r[d].lengths = len;
+    r[d].dgx = dgx[d]; r[d].dgh = (cell == CELL_GRU) ? dgh[d] : nullptr;
+    r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
+  }
+  CVAE_TRY(launch_rnn_backward_multi(r, 2, s));
+  for (int d = 0; d < 2; ++d) {
+    const float* W_ih = w[4 * d + 0];
+    const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
     // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
-    const float* hprev = hs_d + (d ? BH : 0);
+    const float* hprev = r[d].hs + (d ? BH : 0);
     CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s));
     CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
-    CVAE_TRY(grad_weight(dgx, (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s));
-    CVAE_TRY(grad_bias(dgx, L * B, G * H, (long)G * H, dw[4 * d + 2], s));
-    CVAE_TRY(grad_input(dgx, (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s));
+    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s));
+    CVAE_TRY(grad_bias(dgx[d], L * B, G * H, (long)G * H, dw[4 * d + 2], s));
+    CVAE_TRY(grad_input(dgx[d], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s));
   }
   CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ids, dX, mask, mask_rows, demb, s));
   return 0;
 }
 
 // ------------------------------------------------------------------------------ decoder
+struct DecTrainFwd {
+  const float* init; const float* mask_in; const float* mask_out; const float* const* w;
+  float *X, *xproj, *hs, *cs, *gates, *hdrop, *final;
+};
+
+// nd decoders with identical shapes (the stochastic and the coupled deterministic one) advance
+// in the same launches: their recurrences are independent.
+static int decoder_train_forward(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go, const float* emb,
+                                 const DecTrainFwd* dd, float* hp, hipStream_t s) {
+  const int G = gates_of(cell);
+  const long BH = (long)B * Hd, GH = (long)G * Hd;
+  RnnFwd f[SKINNY_MAX_BATCH] = {};
+  for (int d = 0; d < nd; ++d) {
+    const DecTrainFwd& q = dd[d];
+    CVAE_REQUIRE(q.init && q.w && q.X && q.xproj && q.hs && q.gates && q.final, "decoder_forward(train): null operand");
+    CVAE_REQUIRE(cell == CELL_GRU || q.cs, "decoder_forward: LSTM needs cs");
+    CVAE_REQUIRE(q.mask_out == nullptr || q.hdrop, "decoder_forward(train): hdrop missing");
+    CVAE_TRY(launch_embed(T, B, E, 1, 1, go, B, emb, q.init, q.mask_in, nullptr, q.X, s));
+    CVAE_TRY(linear_nt(q.X, q.w[0], 2L * E, q.w[2], ACT_NONE, (T + 1) * B, (int)GH, 2 * E, q.xproj, s));
+    f[d].cell = cell; f[d].T = T + 1; f[d].R = B; f[d].H = Hd; f[d].xproj = q.xproj; f[d].xmod = B;
+    f[d].W_hh = q.w[1]; f[d].b_hh = q.w[3]; f[d].hs = q.hs; f[d].cs = q.cs; f[d].gates = q.gates; f[d].hp_scratch = hp;
+  }
+  CVAE_TRY(launch_rnn_forward_multi(f, nd, s));
+  for (int d = 0; d < nd; ++d) {
+    const DecTrainFwd& q = dd[d];
+    const float* hout = q.hs + 2 * BH;
+    if (q.mask_out) {
+      CVAE_TRY(launch_mul((long)T * BH, hout, q.mask_out, q.hdrop, s));
+      hout = q.hdrop;
+    }
+    CVAE_TRY(linear_nt(hout, q.w[4], Hd, q.w[5], ACT_TANH, T * B, E, Hd, q.final, s));
+  }
+  return 0;
+}
+
 int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd, int64_t V, const float* init,
                          const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
                          const float* const* w, float* X, float* xproj, float* xadd, float* hp, float* hs,
@@ -262,57 +304,112 @@ int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd
                "decoder_forward: bad shape B=%d R=%d T=%d E=%d Hd=%d", B, R, T, E, Hd);
   CVAE_REQUIRE(init && go && emb && w && X && xproj && hs && final, "decoder_forward: null operand");
   CVAE_REQUIRE(cell == CELL_GRU || cs, "decoder_forward: LSTM needs cs");
+  CVAE_REQUIRE(R <= SKINNY_MAX_ROWS || hp, "decoder_forward: hp scratch required for R > %d", SKINNY_MAX_ROWS);
   const int G = gates_of(cell);
   const float* W_ih = w[0]; const float* W_hh = w[1]; const float* b_ih = w[2]; const float* b_hh = w[3];
   const float* W_c = w[4]; const float* b_c = w[5];
   const long RH = (long)R * Hd, GH = (long)G * Hd;
-  const float* hout;     // [T,R,Hd] input of W_c
   if (train) {
     CVAE_REQUIRE(R == B, "decoder_forward(train): R must equal B");
-    CVAE_REQUIRE(gates && (mask_out == nullptr || hdrop), "decoder_forward(train): gates / hdrop missing");
-    CVAE_REQUIRE(R <= SKINNY_MAX_ROWS || hp, "decoder_forward: hp scratch required for R > %d", SKINNY_MAX_ROWS);
-    CVAE_TRY(launch_embed(T, B, E, 1, 1, go, B, emb, init, mask_in, nullptr, X, s));
-    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, (T + 1) * B, (int)GH, 2 * E, xproj, s));
-    RnnFwd f = {};
-    f.cell = cell; f.T = T + 1; f.R = R; f.H = Hd; f.xproj = xproj; f.xmod = R;
-    f.W_hh = W_hh; f.b_hh = b_hh; f.hs = hs; f.cs = cs; f.gates = gates; f.hp_scratch = hp;
-    CVAE_TRY(launch_rnn_forward(f, s));
-    hout = hs + 2 * RH;
-    if (mask_out) {
-      CVAE_TRY(launch_mul((long)T * RH, hout, mask_out, hdrop, s));
-      hout = hdrop;
-    }
-  } else {
-    CVAE_REQUIRE(!mask_in && !mask_out, "decoder_forward(eval): dropout masks given");
-    CVAE_REQUIRE(xadd, "decoder_forward(eval): xadd missing");
-    CVAE_REQUIRE(R <= SKINNY_MAX_ROWS || hp, "decoder_forward: hp scratch required for R > %d", SKINNY_MAX_ROWS);
-    // x-side pre-activations, de-duplicated:
-    //   steps 1..T : W_ih[:, :E] emb(go_t) + b_ih (per sentence)  +  W_ih[:, E:] init (per row, time-invariant)
-    //   step 0     : W_ih[:, :E] init + b_ih (per row)            +  the same time-invariant part
-    float* xinit = xadd;            // [R, G*Hd]
-    float* x0 = xadd + (long)R * GH;  // [R, G*Hd]
-    CVAE_TRY(launch_embed(T, B, E, 0, 0, go, B, emb, nullptr, nullptr, nullptr, X, s));
-    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, T * B, (int)GH, E, xproj, s));
-    CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, R, (int)GH, E, xinit, s));
-    CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, R, (int)GH, E, x0, s));
-    RnnFwd f0 = {};
-    f0.cell = cell; f0.T = 1; f0.R = R; f0.H = Hd; f0.xproj = x0; f0.xmod = R; f0.xadd = xinit;
-    f0.W_hh = W_hh; f0.b_hh = b_hh; f0.hs = hs; f0.cs = cs; f0.hp_scratch = hp;
-    CVAE_TRY(launch_rnn_forward(f0, s));
-    RnnFwd f = f0;
-    f.T = T; f.xproj = xproj; f.xmod = B; f.hs = hs + RH; f.cs = cs ? cs + RH : nullptr;
-    f.init_in_place = 1;                               // slot 0 of this view = h_0 from the prefix step
-    CVAE_TRY(launch_rnn_forward(f, s));
-    hout = hs + 2 * RH;
+    DecTrainFwd q = {init, mask_in, mask_out, w, X, xproj, hs, cs, gates, hdrop, final};
+    return decoder_train_forward(1, cell, B, T, E, Hd, go, emb, &q, hp, s);
   }
-  CVAE_TRY(linear_nt(hout, W_c, Hd, b_c, ACT_TANH, T * R, E, Hd, final, s));
-  return 0;
+  CVAE_REQUIRE(!mask_in && !mask_out, "decoder_forward(eval): dropout masks given");
+  CVAE_REQUIRE(xadd, "decoder_forward(eval): xadd missing");
+  // x-side pre-activations, de-duplicated:
+  //   steps 1..T : W_ih[:, :E] emb(go_t) + b_ih (per sentence)  +  W_ih[:, E:] init (per row, time-invariant)
+  //   step 0     : W_ih[:, :E] init + b_ih (per row)            +  the same time-invariant part
+  float* xinit = xadd;              // [R, G*Hd]
+  float* x0 = xadd + (long)R * GH;  // [R, G*Hd]
+  CVAE_TRY(launch_embed(T, B, E, 0, 0, go, B, emb, nullptr, nullptr, nullptr, X, s));
+  CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, T * B, (int)GH, E, xproj, s));
+  CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, R, (int)GH, E, xinit, s));
+  CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, R, (int)GH, E, x0, s));
+  RnnFwd f0 = {};
+  f0.cell = cell; f0.T = 1; f0.R = R; f0.H = Hd; f0.xproj = x0; f0.xmod = R; f0.xadd = xinit;
+  f0.W_hh = W_hh; f0.b_hh = b_hh; f0.hs = hs; f0.cs = cs; f0.hp_scratch = hp;
+  CVAE_TRY(launch_rnn_forward(f0, s));
+  RnnFwd f = f0;
+  f.T = T; f.xproj = xproj; f.xmod = B; f.hs = hs + RH; f.cs = cs ? cs + RH : nullptr;
+  f.init_in_place = 1;                               // slot 0 of this view = h_0 from the prefix step
+  CVAE_TRY(launch_rnn_forward(f, s));
+  return linear_nt(hs + 2 * RH, W_c, Hd, b_c, ACT_TANH, T * R, E, Hd, final, s);
+}
+
+int cvae_decoder_forward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const float* const* init,
+                           const int64_t* go, const float* emb, const float* const* mask_in,
+                           const float* const* mask_out, const float* const* w, float* const* X,
+                           float* const* xproj, float* const* hs, float* const* cs, float* const* gates,
+                           float* const* hdrop, float* const* final, void* stream) {
+  CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH, "decoder_forward_n: nd=%d (max %d)", nd, SKINNY_MAX_BATCH);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_forward_n: bad cell");
+  CVAE_REQUIRE(B > 0 && B <= SKINNY_MAX_ROWS && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_forward_n: bad shape");
+  CVAE_REQUIRE(init && go && emb && w && X && xproj && hs && gates && final, "decoder_forward_n: null operand");
+  DecTrainFwd q[SKINNY_MAX_BATCH];
+  for (int d = 0; d < nd; ++d)
+    q[d] = {init[d], mask_in ? mask_in[d] : nullptr, mask_out ? mask_out[d] : nullptr, w + 6 * d, X[d], xproj[d],
+            hs[d], cs ? cs[d] : nullptr, gates[d], hdrop ? hdrop[d] : nullptr, final[d]};
+  return decoder_train_forward(nd, cell, B, T, E, Hd, go, emb, q, nullptr, S(stream));
 }
 
 int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd) {
   const int64_t G = gates_of(cell), T1 = T + 1;
-  // dpre [T,B,E] + dhs [(T+1),B,Hd] + dgx,dgh [(T+1),B,G*Hd] + dX [(T+1),B,2E] + 4 x [B,Hd]
-  return (int64_t)T * B * E + T1 * B * Hd + 2 * T1 * B * G * Hd + T1 * B * 2 * E + 4 * (int64_t)B * Hd;
+  // dpre [T,B,E] + dhs [(T+1),B,Hd] + dgx,dgh [(T+1),B,G*Hd] + dX [(T+1),B,2E] + 4 x [B,Hd] + W_hh^T
+  return (int64_t)T * B * E + T1 * B * Hd + 2 * T1 * B * G * Hd + T1 * B * 2 * E + 4 * (int64_t)B * Hd +
+         G * (int64_t)Hd * Hd;
+}
+
+struct DecBwd {
+  const float* mask_in; const float* mask_out; const float* const* w;
+  const float *X, *hs, *cs, *gates, *hdrop, *final, *dfinal;
+  float* dinit; float* const* dw; float* scratch;
+};
+
+static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go,
+                                 const DecBwd* dd, float* demb, hipStream_t s) {
+  const int G = gates_of(cell), T1 = T + 1;
+  const long BH = (long)B * Hd, GH = (long)G * Hd;
+  RnnBwd r[SKINNY_MAX_BATCH] = {};
+  float* dgx[SKINNY_MAX_BATCH]; float* dgh[SKINNY_MAX_BATCH]; float* dX[SKINNY_MAX_BATCH];
+  for (int d = 0; d < nd; ++d) {
+    const DecBwd& q = dd[d];
+    CVAE_REQUIRE(q.w && q.X && q.hs && q.gates && q.final && q.dfinal && q.dinit && q.dw && q.scratch,
+                 "decoder_backward: null operand");
+    CVAE_REQUIRE(!q.mask_out || q.hdrop, "decoder_backward: hdrop missing");
+    float* dpre = q.scratch;
+    float* dhs = dpre + (long)T * B * E;
+    dgx[d] = dhs + (long)T1 * BH;
+    dgh[d] = dgx[d] + (long)T1 * B * GH;
+    dX[d] = dgh[d] + (long)T1 * B * GH;
+    float* dh0 = dX[d] + (long)T1 * B * 2 * E;
+    float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+    float* whhT = dc_tmp + BH;
+    const float* hout = q.mask_out ? q.hdrop : q.hs + 2 * BH;
+    // final = tanh(hout W_c^T + b_c)
+    CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre, s));
+    CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, q.dw[4], 0, s));
+    CVAE_TRY(grad_bias(dpre, T * B, E, E, q.dw[5], s));
+    CVAE_TRY(check_hip(hipMemsetAsync(dhs, 0, (size_t)BH * sizeof(float), s), "dhs[0] memset"));
+    CVAE_TRY(grad_input(dpre, E, q.w[4], Hd, T * B, E, Hd, dhs + BH, Hd, 0, s));
+    if (q.mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, q.mask_out, dhs + BH, s));
+    r[d].cell = cell; r[d].T = T1; r[d].R = B; r[d].H = Hd; r[d].reverse = 0;
+    r[d].dhs = dhs; r[d].hs = q.hs; r[d].cs = q.cs; r[d].gates = q.gates; r[d].W_hh = q.w[1];
+    r[d].dgx = dgx[d]; r[d].dgh = (cell == CELL_GRU) ? dgh[d] : nullptr;
+    r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
+  }
+  CVAE_TRY(launch_rnn_backward_multi(r, nd, s));
+  for (int d = 0; d < nd; ++d) {
+    const DecBwd& q = dd[d];
+    const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
+    CVAE_TRY(grad_weight(dgh_eff, GH, q.hs, Hd, T1 * B, (int)GH, Hd, q.dw[1], 0, s));
+    CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, q.dw[3], s));
+    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s));
+    CVAE_TRY(grad_bias(dgx[d], T1 * B, (int)GH, GH, q.dw[2], s));
+    CVAE_TRY(grad_input(dgx[d], GH, q.w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, s));
+    CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], q.mask_in, q.dinit, s));
+    CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], q.mask_in, nullptr, demb, s));
+  }
+  return 0;
 }
 
 int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
@@ -320,45 +417,30 @@ int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, cons
                           const float* hs, const float* cs, const float* gates, const float* hdrop,
                           const float* final, const float* dfinal, float* dinit, float* const* dw, float* demb,
                           float* scratch, void* stream) {
-  hipStream_t s = S(stream);
   CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_backward: bad cell");
   CVAE_REQUIRE(B > 0 && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward: bad shape");
+  CVAE_REQUIRE(go && demb, "decoder_backward: null operand");
+  DecBwd q = {mask_in, mask_out, w, X, hs, cs, gates, hdrop, final, dfinal, dinit, dw, scratch};
+  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream));
+}
+
+int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                            const float* const* mask_in, const float* const* mask_out, const float* const* w,
+                            const float* const* X, const float* const* hs, const float* const* cs,
+                            const float* const* gates, const float* const* hdrop, const float* const* final,
+                            const float* const* dfinal, float* const* dinit, float* const* dw, float* demb,
+                            float* const* scratch, void* stream) {
+  CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH, "decoder_backward_n: nd=%d (max %d)", nd, SKINNY_MAX_BATCH);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_backward_n: bad cell");
+  CVAE_REQUIRE(B > 0 && B <= SKINNY_MAX_ROWS && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward_n: bad shape");
   CVAE_REQUIRE(go && w && X && hs && gates && final && dfinal && dinit && dw && demb && scratch,
-               "decoder_backward: null operand");
-  CVAE_REQUIRE(!mask_out || hdrop, "decoder_backward: hdrop missing");
-  const int G = gates_of(cell), T1 = T + 1;
-  const long BH = (long)B * Hd, GH = (long)G * Hd;
-  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* W_c = w[4];
-  float* dpre = scratch;
-  float* dhs = dpre + (long)T * B * E;
-  float* dgx = dhs + (long)T1 * BH;
-  float* dgh = dgx + (long)T1 * B * GH;
-  float* dX = dgh + (long)T1 * B * GH;
-  float* dh0 = dX + (long)T1 * B * 2 * E;
-  float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
-  const float* hout = mask_out ? hdrop : hs + 2 * BH;
-  // final = tanh(hout W_c^T + b_c)
-  CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, final, dfinal, dpre, s));
-  CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, dw[4], 0, s));
-  CVAE_TRY(grad_bias(dpre, T * B, E, E, dw[5], s));
-  CVAE_TRY(check_hip(hipMemsetAsync(dhs, 0, (size_t)BH * sizeof(float), s), "dhs[0] memset"));
-  CVAE_TRY(grad_input(dpre, E, W_c, Hd, T * B, E, Hd, dhs + BH, Hd, 0, s));
-  if (mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, mask_out, dhs + BH, s));
-  RnnBwd r = {};
-  r.cell = cell; r.T = T1; r.R = B; r.H = Hd; r.reverse = 0;
-  r.dhs = dhs; r.hs = hs; r.cs = cs; r.gates = gates; r.W_hh = W_hh;
-  r.dgx = dgx; r.dgh = (cell == CELL_GRU) ? dgh : nullptr;
-  r.dh0 = dh0; r.dc0 = dc0; r.dh_tmp = dh_tmp; r.dc_tmp = dc_tmp;
-  CVAE_TRY(launch_rnn_backward(r, s));
-  const float* dgh_eff = (cell == CELL_GRU) ? dgh : dgx;
-  CVAE_TRY(grad_weight(dgh_eff, GH, hs, Hd, T1 * B, (int)GH, Hd, dw[1], 0, s));
-  CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, dw[3], s));
-  CVAE_TRY(grad_weight(dgx, GH, X, 2L * E, T1 * B, (int)GH, 2 * E, dw[0], 0, s));
-  CVAE_TRY(grad_bias(dgx, T1 * B, (int)GH, GH, dw[2], s));
-  CVAE_TRY(grad_input(dgx, GH, W_ih, 2L * E, T1 * B, (int)GH, 2 * E, dX, 2L * E, 0, s));
-  CVAE_TRY(launch_dec_dinit(T, B, E, dX, mask_in, dinit, s));
-  CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX, mask_in, nullptr, demb, s));
-  return 0;
+               "decoder_backward_n: null operand");
+  DecBwd q[SKINNY_MAX_BATCH];
+  for (int d = 0; d < nd; ++d)
+    q[d] = {mask_in ? mask_in[d] : nullptr, mask_out ? mask_out[d] : nullptr, w + 6 * d, X[d], hs[d],
+            cs ? cs[d] : nullptr, gates[d], hdrop ? hdrop[d] : nullptr, final[d], dfinal[d], dinit[d], dw + 6 * d,
+            scratch[d]};
+  return decoder_backward_impl(nd, cell, B, T, E, Hd, go, q, demb, S(stream));
 }
 
 // ------------------------------------------------------------------------------ projection + CE

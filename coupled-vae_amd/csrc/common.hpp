@@ -90,7 +90,7 @@ struct GemmDesc {
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
 // Few-row product with the K dimension split over the waves of a block (skinny.hip).
-enum SkinnyEpi { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2 };
+enum SkinnyEpi { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2, EPI_GRU_BWD = 3, EPI_LSTM_BWD = 4 };
 struct SkinnyArgs {
   const float* A; long lda;            // [M,K], k contiguous
   const float* B; long ldb; int transB;  // op(B) KxN: transB=1 -> B[n*ldb+k], 0 -> B[k*ldb+n]
@@ -106,8 +106,23 @@ struct SkinnyArgs {
   float* h_out; float* c_out;          // [M,H]
   float* gates; long ldg;              // optional [M, 4H]: GRU r,z,n,(W_hn h + b_hn); LSTM i,f,g,o
   const int64_t* lengths; int t;       // optional: row r is updated only while t < lengths[r]
+  // EPI_*_BWD: A = dG_h of step t (K = G*H), B = W_hh^T [H, G*H] (transB = 1), N = H.
+  //   dh = A.op(B) + dh_buf (+ dhs_prev) is the full gradient wrt the output of the PREVIOUS step
+  //   (forward order); when has_prev the epilogue runs that step's cell backward in place:
+  //   writes dgx_prev / dgh_prev, leaves the direct carry in dh_buf (and dc in dc_buf).
+  //   When !has_prev it just stores dh into dh_buf (= gradient wrt the initial state).
+  float* dh_buf; float* dc_buf;        // [M,H] in/out
+  const float* dhs_prev;               // [M,H] or null
+  const float* gates_prev;             // [M,4H]
+  const float* hin_prev; const float* cin_prev; const float* cout_prev;   // state in / out of the previous step
+  float* dgx_prev; float* dgh_prev;    // [M,G*H]; dgh_prev null for LSTM (same as dgx)
+  int has_prev, t_prev;
 };
 int launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+// n <= 4 independent problems of identical shape in ONE launch (blockIdx.z picks the problem):
+// lock-step timesteps of independent recurrences (two encoder directions, two decoders).
+constexpr int SKINNY_MAX_BATCH = 4;
+int launch_skinny_multi(const SkinnyArgs* a, int n, int epi, hipStream_t s);
 
 
 // One direction of a 1-layer GRU/LSTM over T steps (rnn.hip).  State slots: hs/cs hold T+1
@@ -127,6 +142,8 @@ struct RnnFwd {
   float* hp_scratch;                // [R,G*H]; required when R > SKINNY_MAX_ROWS
 };
 int launch_rnn_forward(const RnnFwd& a, hipStream_t s);
+// ns independent sequences with the same cell / T / R / H, advanced in lock-step
+int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s);
 
 struct RnnBwd {
   int cell, T, R, H, reverse;
@@ -137,8 +154,10 @@ struct RnnBwd {
   const int64_t* lengths;
   float* dgx; float* dgh;           // [T,R,G*H] pre-activation grads, x side / h side (LSTM: dgh may be null = dgx)
   float* dh0; float* dc0;           // [R,H] out: grad wrt the initial state
-  float* dh_tmp; float* dc_tmp;     // [R,H] scratch
+  float* whhT;                      // [H, G*H] scratch: W_hh transposed (needed when R <= SKINNY_MAX_ROWS)
+  float* dh_tmp; float* dc_tmp;     // [R,H] scratch (large-R path only)
 };
 int launch_rnn_backward(const RnnBwd& a, hipStream_t s);
+int launch_rnn_backward_multi(const RnnBwd* a, int ns, hipStream_t s);
 
 }  // namespace cvae

@@ -11,6 +11,7 @@
 // timesteps at once, done by the caller (api.hip).
 // Packed sequences (encoder) are handled by masking: a row is updated only while t < len.
 #include "common.hpp"
+#include "cell_math.hpp"
 
 namespace cvae {
 
@@ -62,127 +63,230 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(
   }
 }
 
-int launch_rnn_forward(const RnnFwd& a, hipStream_t s) {
+static int rnn_forward_check(const RnnFwd& a) {
   CVAE_REQUIRE(a.cell == CELL_GRU || a.cell == CELL_LSTM, "rnn_forward: bad cell %d", a.cell);
   CVAE_REQUIRE(a.T >= 0 && a.R > 0 && a.H > 0 && a.xmod > 0, "rnn_forward: bad shape T=%d R=%d H=%d", a.T, a.R, a.H);
   CVAE_REQUIRE(a.xproj && a.W_hh && a.b_hh && a.hs, "rnn_forward: null operand");
   CVAE_REQUIRE(a.cell == CELL_GRU || a.cs, "rnn_forward: LSTM needs cs");
   CVAE_REQUIRE(a.R % a.xmod == 0, "rnn_forward: R must be a multiple of xmod");
-  const int G = a.cell == CELL_GRU ? 3 : 4;
+  CVAE_REQUIRE(a.R <= SKINNY_MAX_ROWS || a.hp_scratch, "rnn_forward: hp_scratch required for R > %d", SKINNY_MAX_ROWS);
+  return 0;
+}
+
+static int rnn_forward_init(const RnnFwd& a, hipStream_t s) {
   const long RH = (long)a.R * a.H;
-  const bool small = a.R <= SKINNY_MAX_ROWS;
-  CVAE_REQUIRE(small || a.hp_scratch, "rnn_forward: hp_scratch required for R > %d", SKINNY_MAX_ROWS);
   const int init_slot = a.reverse ? a.T : 0;
-  if (a.init_in_place) {
-    // nothing to do
-  } else if (a.h0) CVAE_TRY(check_hip(hipMemcpyAsync(a.hs + init_slot * RH, a.h0, RH * 4, hipMemcpyDeviceToDevice, s), "h0 copy"));
+  if (a.init_in_place) return 0;
+  if (a.h0) CVAE_TRY(check_hip(hipMemcpyAsync(a.hs + init_slot * RH, a.h0, RH * 4, hipMemcpyDeviceToDevice, s), "h0 copy"));
   else CVAE_TRY(check_hip(hipMemsetAsync(a.hs + init_slot * RH, 0, RH * 4, s), "h0 memset"));
-  if (a.cell == CELL_LSTM && !a.init_in_place) {
+  if (a.cell == CELL_LSTM) {
     if (a.c0) CVAE_TRY(check_hip(hipMemcpyAsync(a.cs + init_slot * RH, a.c0, RH * 4, hipMemcpyDeviceToDevice, s), "c0 copy"));
     else CVAE_TRY(check_hip(hipMemsetAsync(a.cs + init_slot * RH, 0, RH * 4, s), "c0 memset"));
-  }
-  for (int i = 0; i < a.T; ++i) {
-    const int t = a.reverse ? a.T - 1 - i : i;
-    const int in_slot = a.reverse ? t + 1 : t, out_slot = a.reverse ? t : t + 1;
-    const float* hprev = a.hs + in_slot * RH;
-    const float* cprev = a.cs ? a.cs + in_slot * RH : nullptr;
-    float* hout = a.hs + out_slot * RH;
-    float* cout = a.cs ? a.cs + out_slot * RH : nullptr;
-    const float* xp = a.xproj + (long)t * a.xmod * G * a.H;
-    float* gates = a.gates ? a.gates + (long)t * a.R * 4 * a.H : nullptr;
-    if (small) {
-      SkinnyArgs k = {};
-      k.A = hprev; k.lda = a.H; k.B = a.W_hh; k.ldb = a.H; k.transB = 1;
-      k.M = a.R; k.N = a.H; k.K = a.H; k.ngroups = G; k.gstride = a.H;
-      k.xproj = xp; k.ldx = (long)G * a.H; k.xmod = a.xmod; k.xadd = a.xadd; k.b_hh = a.b_hh;
-      k.h_prev = hprev; k.c_prev = cprev; k.h_out = hout; k.c_out = cout;
-      k.gates = gates; k.ldg = 4L * a.H; k.lengths = a.lengths; k.t = t;
-      CVAE_TRY(launch_skinny(k, a.cell == CELL_GRU ? EPI_GRU : EPI_LSTM, s));
-    } else {
-      GemmDesc d = {};
-      d.transA = 0; d.transB = 1; d.M = a.R; d.N = G * a.H; d.K = a.H;
-      d.A = hprev; d.lda = a.H; d.B = a.W_hh; d.ldb = a.H; d.C = a.hp_scratch; d.ldc = (long)G * a.H;
-      CVAE_TRY(launch_gemm(d, s));
-      const int grid = cdiv(RH, 256);
-      // algorithmic bytes: hp + x-side (G each) + h_prev in, h out (+ c in/out for LSTM)
-      ProfScope prof(PK_CELL_FWD, s, 4.0 * RH * (2 * G + 2 + (a.cell == CELL_LSTM ? 2 : 0)));
-      if (a.cell == CELL_GRU)
-        hipLaunchKernelGGL((cell_fwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, xp,
-                           a.xmod, a.xadd, a.b_hh, hprev, cprev, hout, cout, gates, a.lengths, t);
-      else
-        hipLaunchKernelGGL((cell_fwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, xp,
-                           a.xmod, a.xadd, a.b_hh, hprev, cprev, hout, cout, gates, a.lengths, t);
-      CVAE_LAUNCH_CHECK("cell_fwd_kernel");
-    }
   }
   return 0;
 }
 
+// arguments of step i (processing order) of one sequence
+static void rnn_forward_step_args(const RnnFwd& a, int i, SkinnyArgs& k) {
+  const int G = a.cell == CELL_GRU ? 3 : 4;
+  const long RH = (long)a.R * a.H;
+  const int t = a.reverse ? a.T - 1 - i : i;
+  const int in_slot = a.reverse ? t + 1 : t, out_slot = a.reverse ? t : t + 1;
+  k = SkinnyArgs{};
+  k.A = a.hs + in_slot * RH; k.lda = a.H; k.B = a.W_hh; k.ldb = a.H; k.transB = 1;
+  k.M = a.R; k.N = a.H; k.K = a.H; k.ngroups = G; k.gstride = a.H;
+  k.xproj = a.xproj + (long)t * a.xmod * G * a.H; k.ldx = (long)G * a.H; k.xmod = a.xmod; k.xadd = a.xadd;
+  k.b_hh = a.b_hh;
+  k.h_prev = k.A; k.c_prev = a.cs ? a.cs + in_slot * RH : nullptr;
+  k.h_out = a.hs + out_slot * RH; k.c_out = a.cs ? a.cs + out_slot * RH : nullptr;
+  k.gates = a.gates ? a.gates + (long)t * a.R * 4 * a.H : nullptr; k.ldg = 4L * a.H;
+  k.lengths = a.lengths; k.t = t;
+}
+
+static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
+  const int G = a.cell == CELL_GRU ? 3 : 4;
+  const long RH = (long)a.R * a.H;
+  for (int i = 0; i < a.T; ++i) {
+    SkinnyArgs k;
+    rnn_forward_step_args(a, i, k);
+    GemmDesc d = {};
+    d.transA = 0; d.transB = 1; d.M = a.R; d.N = G * a.H; d.K = a.H;
+    d.A = k.A; d.lda = a.H; d.B = a.W_hh; d.ldb = a.H; d.C = a.hp_scratch; d.ldc = (long)G * a.H;
+    CVAE_TRY(launch_gemm(d, s));
+    const int grid = cdiv(RH, 256);
+    // algorithmic bytes: hp + x-side (G each) + h_prev in, h out (+ c in/out for LSTM)
+    ProfScope prof(PK_CELL_FWD, s, 4.0 * RH * (2 * G + 2 + (a.cell == CELL_LSTM ? 2 : 0)));
+    if (a.cell == CELL_GRU)
+      hipLaunchKernelGGL((cell_fwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, k.xproj,
+                         a.xmod, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
+    else
+      hipLaunchKernelGGL((cell_fwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, k.xproj,
+                         a.xmod, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
+    CVAE_LAUNCH_CHECK("cell_fwd_kernel");
+  }
+  return 0;
+}
+
+int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
+  CVAE_REQUIRE(ns >= 1 && ns <= SKINNY_MAX_BATCH, "rnn_forward: %d sequences (max %d)", ns, SKINNY_MAX_BATCH);
+  for (int q = 0; q < ns; ++q) {
+    CVAE_TRY(rnn_forward_check(a[q]));
+    CVAE_REQUIRE(a[q].cell == a[0].cell && a[q].T == a[0].T && a[q].R == a[0].R && a[q].H == a[0].H,
+                 "rnn_forward: lock-step sequences differ in shape");
+    CVAE_TRY(rnn_forward_init(a[q], s));
+  }
+  if (a[0].R > SKINNY_MAX_ROWS) {
+    for (int q = 0; q < ns; ++q) CVAE_TRY(rnn_forward_large(a[q], s));
+    return 0;
+  }
+  SkinnyArgs k[SKINNY_MAX_BATCH];
+  for (int i = 0; i < a[0].T; ++i) {
+    for (int q = 0; q < ns; ++q) rnn_forward_step_args(a[q], i, k[q]);
+    CVAE_TRY(launch_skinny_multi(k, ns, a[0].cell == CELL_GRU ? EPI_GRU : EPI_LSTM, s));
+  }
+  return 0;
+}
+
+int launch_rnn_forward(const RnnFwd& a, hipStream_t s) { return launch_rnn_forward_multi(&a, 1, s); }
+
 // ------------------------------------------------------------------ backward cell
 // dh_in = dh_acc + dhs_t.  Writes the pre-activation gradients of step t and the direct
-// (non-GEMM) part of dh_{t-1} / dc_{t-1} into the *next* accumulators.
+// (non-GEMM) part of dh_{t-1} / dc_{t-1} into the *next* accumulators (may alias the inputs).
 template <int CELL>
 __global__ __launch_bounds__(256) void cell_bwd_kernel(
-    int R, int H, const float* __restrict__ dh_acc, const float* __restrict__ dc_acc,
-    const float* __restrict__ dhs_t, const float* __restrict__ gates,
-    const float* __restrict__ h_prev, const float* __restrict__ c_prev, const float* __restrict__ c_cur,
-    float* __restrict__ dgx, float* __restrict__ dgh, float* __restrict__ dh_next,
-    float* __restrict__ dc_next, const int64_t* __restrict__ lengths, int t) {
+    int R, int H, const float* dh_acc, const float* dc_acc, const float* __restrict__ dhs_t,
+    const float* __restrict__ gates, const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+    const float* __restrict__ c_cur, float* __restrict__ dgx, float* __restrict__ dgh, float* dh_next,
+    float* dc_next, const int64_t* __restrict__ lengths, int t) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)R * H) return;
   const int r = (int)(idx / H), n = (int)(idx % H);
   const bool live = (lengths == nullptr) || ((int64_t)t < lengths[r]);
   const float dh = dh_acc[idx] + (dhs_t ? dhs_t[idx] : 0.f);
-  const float* gp = gates + (long)r * 4 * H + n;
-  float* ox = dgx + (long)r * G * H + n;
-  float* oh = dgh ? dgh + (long)r * G * H + n : nullptr;
-  if constexpr (CELL == CELL_GRU) {
-    if (!live) {
-      ox[0] = ox[H] = ox[2 * H] = 0.f;
-      oh[0] = oh[H] = oh[2 * H] = 0.f;
-      dh_next[idx] = dh;
-      return;
-    }
-    const float rg = gp[0], zg = gp[H], nn = gp[2 * H], hn = gp[3 * H];
-    const float hprev = h_prev[idx];
-    const float dn_pre = dh * (1.f - zg) * (1.f - nn * nn);
-    const float dz_pre = dh * (hprev - nn) * zg * (1.f - zg);
-    const float dr_pre = dn_pre * hn * rg * (1.f - rg);
-    ox[0] = dr_pre; ox[H] = dz_pre; ox[2 * H] = dn_pre;
-    oh[0] = dr_pre; oh[H] = dz_pre; oh[2 * H] = dn_pre * rg;
-    dh_next[idx] = dh * zg;
-  } else {
-    const float dc_in = dc_acc[idx];
-    if (!live) {
-      ox[0] = ox[H] = ox[2 * H] = ox[3 * H] = 0.f;
-      if (oh) oh[0] = oh[H] = oh[2 * H] = oh[3 * H] = 0.f;
-      dh_next[idx] = dh;
-      dc_next[idx] = dc_in;
-      return;
-    }
-    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-    const float tc = tanhf_(c_cur[idx]);
-    const float dc = dc_in + dh * og * (1.f - tc * tc);
-    const float di = dc * gg * ig * (1.f - ig);
-    const float df = dc * c_prev[idx] * fg * (1.f - fg);
-    const float dg = dc * ig * (1.f - gg * gg);
-    const float dout = dh * tc * og * (1.f - og);
-    ox[0] = di; ox[H] = df; ox[2 * H] = dg; ox[3 * H] = dout;
-    if (oh) { oh[0] = di; oh[H] = df; oh[2 * H] = dg; oh[3 * H] = dout; }
-    dh_next[idx] = 0.f;
-    dc_next[idx] = dc * fg;
-  }
+  float dc = (CELL == CELL_LSTM) ? dc_acc[idx] : 0.f;
+  const float direct = cell_bwd_point<CELL>(live, dh, dc, gates + (long)r * 4 * H + n, H, h_prev[idx],
+                                            CELL == CELL_LSTM ? c_prev[idx] : 0.f,
+                                            CELL == CELL_LSTM ? c_cur[idx] : 0.f, dgx + (long)r * G * H + n,
+                                            dgh ? dgh + (long)r * G * H + n : nullptr);
+  dh_next[idx] = direct;
+  if constexpr (CELL == CELL_LSTM) dc_next[idx] = dc;
 }
 
-int launch_rnn_backward(const RnnBwd& a, hipStream_t s) {
-  CVAE_REQUIRE(a.cell == CELL_GRU || a.cell == CELL_LSTM, "rnn_backward: bad cell %d", a.cell);
-  CVAE_REQUIRE(a.T >= 0 && a.R > 0 && a.H > 0, "rnn_backward: bad shape");
-  CVAE_REQUIRE(a.hs && a.gates && a.W_hh && a.dgx && a.dh0 && a.dh_tmp, "rnn_backward: null operand");
-  CVAE_REQUIRE(a.cell == CELL_LSTM || a.dgh, "rnn_backward: GRU needs a separate dgh");
-  CVAE_REQUIRE(a.cell == CELL_GRU || (a.cs && a.dc0 && a.dc_tmp), "rnn_backward: LSTM needs cs / dc0 / dc_tmp");
+// dst[c, r] = src[r, c]
+__global__ __launch_bounds__(256) void transpose_kernel(int R, int C, const float* __restrict__ src,
+                                                        float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(long)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) dst[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+static int launch_cell_bwd(const RnnBwd& a, int t, const float* dh_in, const float* dc_in, float* dh_out,
+                           float* dc_out, hipStream_t s) {
   const int G = a.cell == CELL_GRU ? 3 : 4;
   const long RH = (long)a.R * a.H;
+  const int in_slot = a.reverse ? t + 1 : t, out_slot = a.reverse ? t : t + 1;
+  const long goff = (long)t * a.R * G * a.H;
+  const int grid = cdiv(RH, 256);
+  const float* dhs_t = a.dhs ? a.dhs + (long)t * RH : nullptr;
+  const float* gates = a.gates + (long)t * a.R * 4 * a.H;
+  ProfScope prof(PK_CELL_BWD, s, 4.0 * RH * (4 + 2 * G + 4));
+  if (a.cell == CELL_GRU)
+    hipLaunchKernelGGL((cell_bwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, dh_in, nullptr, dhs_t, gates,
+                       a.hs + in_slot * RH, nullptr, nullptr, a.dgx + goff, a.dgh + goff, dh_out, nullptr, a.lengths,
+                       t);
+  else
+    hipLaunchKernelGGL((cell_bwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, dh_in, dc_in, dhs_t, gates,
+                       a.hs + in_slot * RH, a.cs + in_slot * RH, a.cs + out_slot * RH, a.dgx + goff,
+                       a.dgh ? a.dgh + goff : nullptr, dh_out, dc_out, a.lengths, t);
+  CVAE_LAUNCH_CHECK("cell_bwd_kernel");
+  return 0;
+}
+
+static int rnn_backward_check(const RnnBwd& a) {
+  CVAE_REQUIRE(a.cell == CELL_GRU || a.cell == CELL_LSTM, "rnn_backward: bad cell %d", a.cell);
+  CVAE_REQUIRE(a.T >= 0 && a.R > 0 && a.H > 0, "rnn_backward: bad shape");
+  CVAE_REQUIRE(a.hs && a.gates && a.W_hh && a.dgx && a.dh0, "rnn_backward: null operand");
+  CVAE_REQUIRE(a.cell == CELL_LSTM || a.dgh, "rnn_backward: GRU needs a separate dgh");
+  CVAE_REQUIRE(a.cell == CELL_GRU || (a.cs && a.dc0), "rnn_backward: LSTM needs cs / dc0");
+  return 0;
+}
+
+static int rnn_backward_large(const RnnBwd& a, hipStream_t s);
+
+int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
+  CVAE_REQUIRE(ns >= 1 && ns <= SKINNY_MAX_BATCH, "rnn_backward: %d sequences (max %d)", ns, SKINNY_MAX_BATCH);
+  for (int q = 0; q < ns; ++q) {
+    CVAE_TRY(rnn_backward_check(arr[q]));
+    CVAE_REQUIRE(arr[q].cell == arr[0].cell && arr[q].T == arr[0].T && arr[q].R == arr[0].R && arr[q].H == arr[0].H,
+                 "rnn_backward: lock-step sequences differ in shape");
+  }
+  if (arr[0].R > SKINNY_MAX_ROWS) {
+    for (int q = 0; q < ns; ++q) CVAE_TRY(rnn_backward_large(arr[q], s));
+    return 0;
+  }
+  // ---- one launch per step (for all sequences): dh_{t-1} product with the previous step's cell backward fused in
+  const int T = arr[0].T, H = arr[0].H, R = arr[0].R;
+  const int G = arr[0].cell == CELL_GRU ? 3 : 4;
+  const long RH = (long)R * H;
+  for (int q = 0; q < ns; ++q) {
+    const RnnBwd& a = arr[q];
+    CVAE_REQUIRE(a.whhT, "rnn_backward: whhT scratch required for R <= %d", SKINNY_MAX_ROWS);
+    if (a.dh_last) CVAE_TRY(check_hip(hipMemcpyAsync(a.dh0, a.dh_last, RH * 4, hipMemcpyDeviceToDevice, s), "dh_last copy"));
+    else CVAE_TRY(check_hip(hipMemsetAsync(a.dh0, 0, RH * 4, s), "dh memset"));
+    if (a.cell == CELL_LSTM) {
+      if (a.dc_last) CVAE_TRY(check_hip(hipMemcpyAsync(a.dc0, a.dc_last, RH * 4, hipMemcpyDeviceToDevice, s), "dc_last copy"));
+      else CVAE_TRY(check_hip(hipMemsetAsync(a.dc0, 0, RH * 4, s), "dc memset"));
+    }
+    if (T == 0) continue;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(G * H, 32)), dim3(256), 0, s, G * H, H, a.W_hh, a.whhT);
+    CVAE_LAUNCH_CHECK("transpose_kernel");
+    CVAE_TRY(launch_cell_bwd(a, a.reverse ? 0 : T - 1, a.dh0, a.dc0, a.dh0, a.dc0, s));
+  }
+  SkinnyArgs kk[SKINNY_MAX_BATCH];
+  for (int i = T - 1; i >= 0; --i) {
+    for (int q = 0; q < ns; ++q) {
+      const RnnBwd& a = arr[q];
+      const float* dgh_base = a.dgh ? a.dgh : a.dgx;
+      const int t = a.reverse ? T - 1 - i : i;
+      const bool has_prev = i > 0;
+      const int tp = a.reverse ? t + 1 : t - 1;          // previous step in forward order
+      SkinnyArgs& k = kk[q];
+      k = SkinnyArgs{};
+      k.A = dgh_base + (long)t * R * G * H; k.lda = (long)G * H;
+      k.B = a.whhT; k.ldb = (long)G * H; k.transB = 1;
+      k.M = R; k.N = H; k.K = G * H; k.ngroups = 1; k.gstride = 0;
+      k.dh_buf = a.dh0; k.dc_buf = a.dc0; k.has_prev = has_prev; k.lengths = a.lengths;
+      if (has_prev) {
+        const int in_slot = a.reverse ? tp + 1 : tp, out_slot = a.reverse ? tp : tp + 1;
+        k.t_prev = tp;
+        k.dhs_prev = a.dhs ? a.dhs + (long)tp * RH : nullptr;
+        k.gates_prev = a.gates + (long)tp * R * 4 * H;
+        k.hin_prev = a.hs + in_slot * RH;
+        k.cin_prev = a.cs ? a.cs + in_slot * RH : nullptr;
+        k.cout_prev = a.cs ? a.cs + out_slot * RH : nullptr;
+        k.dgx_prev = a.dgx + (long)tp * R * G * H;
+        k.dgh_prev = a.dgh ? a.dgh + (long)tp * R * G * H : nullptr;
+      }
+    }
+    CVAE_TRY(launch_skinny_multi(kk, ns, arr[0].cell == CELL_GRU ? EPI_GRU_BWD : EPI_LSTM_BWD, s));
+  }
+  return 0;
+}
+
+int launch_rnn_backward(const RnnBwd& a, hipStream_t s) { return launch_rnn_backward_multi(&a, 1, s); }
+
+static int rnn_backward_large(const RnnBwd& a, hipStream_t s) {
+  const int G = a.cell == CELL_GRU ? 3 : 4;
+  const long RH = (long)a.R * a.H;
+  const float* dgh_base = a.dgh ? a.dgh : a.dgx;
+  // ---- large R: pointwise cell backward + accumulate-GEMM per step, ping-pong accumulators
+  CVAE_REQUIRE(a.dh_tmp && (a.cell == CELL_GRU || a.dc_tmp), "rnn_backward: dh_tmp / dc_tmp scratch required");
   float* dhb[2] = {a.dh0, a.dh_tmp};
   float* dcb[2] = {a.dc0, a.dc_tmp};
   int cur = a.T & 1;
@@ -192,40 +296,15 @@ int launch_rnn_backward(const RnnBwd& a, hipStream_t s) {
     if (a.dc_last) CVAE_TRY(check_hip(hipMemcpyAsync(dcb[cur], a.dc_last, RH * 4, hipMemcpyDeviceToDevice, s), "dc_last copy"));
     else CVAE_TRY(check_hip(hipMemsetAsync(dcb[cur], 0, RH * 4, s), "dc memset"));
   }
-  const float* dgh_base = a.dgh ? a.dgh : a.dgx;
   for (int i = a.T - 1; i >= 0; --i) {      // undo the forward order
     const int t = a.reverse ? a.T - 1 - i : i;
-    const int in_slot = a.reverse ? t + 1 : t, out_slot = a.reverse ? t : t + 1;
     const long goff = (long)t * a.R * G * a.H;
-    const int grid = cdiv(RH, 256);
-    const float* dhs_t = a.dhs ? a.dhs + (long)t * RH : nullptr;
-    const float* gates = a.gates + (long)t * a.R * 4 * a.H;
-    {
-    ProfScope prof(PK_CELL_BWD, s, 4.0 * RH * (4 + 2 * G + 4));
-    if (a.cell == CELL_GRU)
-      hipLaunchKernelGGL((cell_bwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, dhb[cur], nullptr, dhs_t,
-                         gates, a.hs + in_slot * RH, nullptr, nullptr, a.dgx + goff, a.dgh + goff, dhb[cur ^ 1],
-                         nullptr, a.lengths, t);
-    else
-      hipLaunchKernelGGL((cell_bwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, dhb[cur], dcb[cur], dhs_t,
-                         gates, a.hs + in_slot * RH, a.cs + in_slot * RH, a.cs + out_slot * RH, a.dgx + goff,
-                         a.dgh ? a.dgh + goff : nullptr, dhb[cur ^ 1], dcb[cur ^ 1], a.lengths, t);
-    }
-    CVAE_LAUNCH_CHECK("cell_bwd_kernel");
-    // dh_{t-1} += dG_h[t] . W_hh      (R x GH) . (GH x H)
-    if (a.R <= SKINNY_MAX_ROWS) {
-      SkinnyArgs k = {};
-      k.A = dgh_base + goff; k.lda = (long)G * a.H; k.B = a.W_hh; k.ldb = a.H; k.transB = 0;
-      k.M = a.R; k.N = a.H; k.K = G * a.H; k.ngroups = 1; k.gstride = 0;
-      k.C = dhb[cur ^ 1]; k.ldc = a.H; k.bias = nullptr; k.act = ACT_NONE; k.beta = 1;
-      CVAE_TRY(launch_skinny(k, EPI_LINEAR, s));
-    } else {
-      GemmDesc d = {};
-      d.transA = 0; d.transB = 0; d.M = a.R; d.N = a.H; d.K = G * a.H;
-      d.A = dgh_base + goff; d.lda = (long)G * a.H; d.B = a.W_hh; d.ldb = a.H;
-      d.C = dhb[cur ^ 1]; d.ldc = a.H; d.beta = 1;
-      CVAE_TRY(launch_gemm(d, s));
-    }
+    CVAE_TRY(launch_cell_bwd(a, t, dhb[cur], dcb[cur], dhb[cur ^ 1], dcb[cur ^ 1], s));
+    GemmDesc d = {};
+    d.transA = 0; d.transB = 0; d.M = a.R; d.N = a.H; d.K = G * a.H;
+    d.A = dgh_base + goff; d.lda = (long)G * a.H; d.B = a.W_hh; d.ldb = a.H;
+    d.C = dhb[cur ^ 1]; d.ldc = a.H; d.beta = 1;
+    CVAE_TRY(launch_gemm(d, s));
     cur ^= 1;
   }
   return 0;

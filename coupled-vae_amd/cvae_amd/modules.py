@@ -198,6 +198,25 @@ class Decoder(nn.Module):
         return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, n_sent)
 
 
+def decode_pair(dec_a, dec_b, init_a, init_b, helper):
+    """Decoder and DecoderCouple on the same `helper` in lock-step (training): same draws, in the
+    reference's order (dec in/out masks, then decc in/out masks), one launch per timestep for both."""
+    R = init_a.shape[0]
+    B, T = helper.shape
+    dev = helper.device
+    specs = []
+    for dec, init, pre in ((dec_a, init_a, 'dec'), (dec_b, init_b, 'decc')):
+        rnn = dec.LSTM if dec.use_lstm else dec.GRU
+        w = _rnn_weights(rnn) + [dec.W_c.weight, dec.W_c.bias]
+        mi = _noise.dropout_mask((T, R, 2 * dec.emb_dim), dec.dropout, dev, pre + '_in_drop')
+        mo = _noise.dropout_mask((T, R, dec.hid_dim), dec.dropout, dev, pre + '_out_drop')
+        specs.append((init, mi, mo, w))
+    cell = ops.LSTM if dec_a.use_lstm else ops.GRU
+    fa, fb = ops.decoder_pair(cell, helper, dec_a.Embedding.weight, specs)
+    return (LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B),
+            LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B))
+
+
 def to_init(seq, x):
     """Linear-ReLU-Linear (vae_couple.py:429-434)."""
     h = ops.linear(x, seq[0].weight, seq[0].bias, ops.ACT_RELU)
@@ -359,8 +378,7 @@ class VAE_COUPLE(_TextBase):
         _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
         init = to_init(self.toInit, z)
         init_c = to_init(self.toInitCouple, mu_c)
-        logits = self.Decoder(None, init, go, _noise_prefix='dec')
-        logits_c = self.DecoderCouple(None, init_c, go, _noise_prefix='decc')
+        logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, go)
         return logits, dist, z, None, logits_c, init, init_c
 
 
@@ -450,8 +468,7 @@ class CVAE_COUPLE(_DialogBase):
         _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
         init = to_init(self.toInit, z) + post_repr
         init_c = to_init(self.toInitCouple, mu_c) + post_repr
-        logits = self.Decoder(None, init, resp_go, _noise_prefix='dec')
-        logits_c = self.DecoderCouple(None, init_c, resp_go, _noise_prefix='decc')
+        logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, resp_go)
         return logits, prior, dist, logits_c, init, init_c
 
 

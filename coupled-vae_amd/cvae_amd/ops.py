@@ -206,6 +206,76 @@ def decoder(cell, train, init, go, mask_in, mask_out, emb, w):
     return DecoderFn.apply(cell, True, init, go, mask_in, mask_out, emb, *w)
 
 
+class DecoderPairFn(torch.autograd.Function):
+    """Two training decoders of identical shape (Decoder / DecoderCouple) advanced in lock-step:
+    every timestep of both recurrences is one launch (cvae_decoder_forward_n).
+    Inputs: cell, go, emb, then for each decoder (init, mask_in, mask_out, 6 weights)."""
+
+    @staticmethod
+    def forward(ctx, cell, go, emb, *rest):
+        nd = len(rest) // 9
+        go, emb = _c(go), _c(emb)
+        per = [[_c(t) for t in rest[9 * d:9 * d + 9]] for d in range(nd)]
+        B, T = go.shape
+        V, E = emb.shape
+        Hd = per[0][4].shape[1]
+        G = gates_of(cell)
+        bufs = []
+        for d in range(nd):
+            mo = per[d][2]
+            bufs.append(dict(X=_f((T + 1, B, 2 * E), emb), xproj=_f((T + 1, B, G * Hd), emb), hs=_f((T + 2, B, Hd), emb),
+                             cs=_f((T + 2, B, Hd), emb) if cell == LSTM else None, gates=_f((T + 1, B, 4 * Hd), emb),
+                             hdrop=_f((T, B, Hd), emb) if mo is not None else None, final=_f((T, B, E), emb)))
+        w_all = [t for d in range(nd) for t in per[d][3:]]
+        arrs = dict(init=ptr_array([per[d][0] for d in range(nd)]), mi=ptr_array([per[d][1] for d in range(nd)]),
+                    mo=ptr_array([per[d][2] for d in range(nd)]), w=ptr_array(w_all))
+        for k in ('X', 'xproj', 'hs', 'cs', 'gates', 'hdrop', 'final'):
+            arrs[k] = ptr_array([b[k] for b in bufs])
+        call('cvae_decoder_forward_n', nd, cell, B, T, E, Hd, V, arrs['init'], ptr(go), ptr(emb), arrs['mi'], arrs['mo'],
+             arrs['w'], arrs['X'], arrs['xproj'], arrs['hs'], arrs['cs'], arrs['gates'], arrs['hdrop'], arrs['final'],
+             stream())
+        ctx.cell, ctx.dims, ctx.nd = cell, (B, T, E, Hd, V), nd
+        saved = [go, emb]
+        for d in range(nd):
+            saved += [per[d][1], per[d][2]] + per[d][3:] + [bufs[d][k] for k in ('X', 'hs', 'cs', 'gates', 'hdrop', 'final')]
+        ctx.save_for_backward(*saved)
+        return tuple(b['final'] for b in bufs)
+
+    @staticmethod
+    def backward(ctx, *dfinals):
+        sv = ctx.saved_tensors
+        go, emb = sv[0], sv[1]
+        nd = ctx.nd
+        B, T, E, Hd, V = ctx.dims
+        per = [sv[2 + 14 * d: 2 + 14 * (d + 1)] for d in range(nd)]   # mi, mo, 6 w, X, hs, cs, gates, hdrop, final
+        dfin = [_c(dfinals[d]) if dfinals[d] is not None else torch.zeros_like(per[d][13]) for d in range(nd)]
+        dinit = [_f((B, E), emb) for _ in range(nd)]
+        dw = [[torch.empty_like(t) for t in per[d][2:8]] for d in range(nd)]
+        demb = torch.zeros_like(emb)
+        nscr = query('cvae_decoder_backward_scratch', ctx.cell, B, T, E, Hd)
+        scr = [_f((nscr,), emb) for _ in range(nd)]
+        pa = lambda idx: ptr_array([per[d][idx] for d in range(nd)])
+        w_all = ptr_array([t for d in range(nd) for t in per[d][2:8]])
+        dw_all = ptr_array([t for d in range(nd) for t in dw[d]])
+        arr_mi, arr_mo, arr_X, arr_hs, arr_cs, arr_g, arr_hd, arr_fin = (pa(0), pa(1), pa(8), pa(9), pa(10), pa(11),
+                                                                          pa(12), pa(13))
+        arr_df, arr_di, arr_scr = ptr_array(dfin), ptr_array(dinit), ptr_array(scr)
+        call('cvae_decoder_backward_n', nd, ctx.cell, B, T, E, Hd, V, ptr(go), arr_mi, arr_mo, w_all, arr_X, arr_hs,
+             arr_cs, arr_g, arr_hd, arr_fin, arr_df, arr_di, dw_all, ptr(demb), arr_scr, stream())
+        out = [None, None, demb]
+        for d in range(nd):
+            out += [dinit[d], None, None] + dw[d]
+        return tuple(out)
+
+
+def decoder_pair(cell, go, emb, specs):
+    """specs: list of (init, mask_in, mask_out, [W_ih, W_hh, b_ih, b_hh, W_c, b_c]) -> list of final (T,B,E)."""
+    flat = []
+    for init, mi, mo, w in specs:
+        flat += [init, mi, mo] + list(w)
+    return DecoderPairFn.apply(cell, go, emb, *flat)
+
+
 # --------------------------------------------------------------------------- projection + CE
 def targets_time_major(eos, R):
     eos = _c(eos)

@@ -97,6 +97,23 @@ int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, cons
                           const float* final, const float* dfinal, float* dinit, float* const* dw, float* demb,
                           float* scratch, void* stream);
 
+/* The same for nd <= 4 decoders of identical shape run in lock-step (training only, R == B):
+ * the stochastic Decoder and the deterministic DecoderCouple of VAE_COUPLE.forward
+ * (Modules/vae_couple.py:733-739) are independent recurrences, so each timestep of both is
+ * ONE launch.  Every per-decoder argument becomes an array of nd pointers; w and dw hold
+ * 6*nd entries (decoder d at [6d, 6d+6)); scratch[d]: cvae_decoder_backward_scratch floats. */
+int cvae_decoder_forward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const float* const* init,
+                           const int64_t* go, const float* emb, const float* const* mask_in,
+                           const float* const* mask_out, const float* const* w, float* const* X,
+                           float* const* xproj, float* const* hs, float* const* cs, float* const* gates,
+                           float* const* hdrop, float* const* final, void* stream);
+int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                            const float* const* mask_in, const float* const* mask_out, const float* const* w,
+                            const float* const* X, const float* const* hs, const float* const* cs,
+                            const float* const* gates, const float* const* hdrop, const float* const* final,
+                            const float* const* dfinal, float* const* dinit, float* const* dw, float* demb,
+                            float* const* scratch, void* stream);
+
 /* ---- a7 tail + a8: ToVocab + SeqLoss(keep_batch=True) (Modules/vae_couple.py:119,
  * Modules/Losses/SeqLoss.py:36-44), fused: logits are never materialised.
  * final[T*R,E] (time-major rows n = t*R + r), W[V,E], b[V], tgt[T*R] (time-major targets),
