@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import ops
+from . import dist_utils, ops
 from .modules import MODEL_CLASSES
 from .settings import settings
 
@@ -160,8 +160,7 @@ class Trainer(object):
         if self.world > 1:
             # the batch mean over equal per-rank batches = mean of per-rank gradients; must
             # complete before the clip (Experiment.py:515 clips the full-batch gradient)
-            dist.all_reduce(self.opt.grads, op=dist.ReduceOp.SUM)
-            self.opt.grads.mul_(1.0 / self.world)
+            dist_utils.allreduce_mean_(self.opt.grads)
         return res
 
     def train_step(self, batch):
@@ -193,8 +192,7 @@ class Trainer(object):
             acc += torch.stack([nll.sum().double(), xent.sum().double(), kl.sum().double(),
                                 (ln + 1).sum().double(), torch.tensor(float(nll.numel()), device=self.device).double()])
             per_sentence.append((xent, nll, kl))
-        if self.world > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist_utils.reduce_sums_(acc)
         a = acc.tolist()
         self.model.train(True)
         return dict(nll=a[0] / a[4], xent=a[1] / a[4], kl=a[2] / a[4], ppl=math.exp(a[0] / a[3]),
@@ -208,8 +206,7 @@ class Trainer(object):
         for b in batches:
             mi, _ = self.model.estimate_mi(go=b['go'], sent_len=b['len'], bare=b['bare'], n_sample=n_sample)
             acc += torch.stack([mi.sum().double(), torch.tensor(float(mi.numel()), device=self.device).double()])
-        if self.world > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist_utils.reduce_sums_(acc)
         self.model.train(True)
         a = acc.tolist()
         return a[0] / max(a[1], 1.0)
