@@ -444,34 +444,55 @@ int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64
 }
 
 // ------------------------------------------------------------------------------ projection + CE
-int64_t cvae_projce_workspace(int64_t N, int64_t V) { return projce_workspace_floats((int)N, (int)V); }
+int64_t cvae_projce_workspace(int64_t N, int64_t E, int64_t V) {
+  if (ce_fast_supported((int)E)) return ce_fast_workspace_floats(N, (int)V);
+  return projce_workspace_floats((int)N, (int)V);
+}
 
 int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                        int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent, float* ws,
-                        void* stream) {
+                        int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                        float* ws, void* stream) {
   hipStream_t s = S(stream);
-  CVAE_REQUIRE(T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V < (1LL << 31), "projce_forward: bad shape");
-  CVAE_TRY(launch_projce_forward(final, W, b, tgt, pad, T * R, E, (int)V, loss_row, lse, ws, s));
-  if (sent) CVAE_TRY(launch_sum_time(loss_row, T, R, sent, s));
+  CVAE_REQUIRE(nseg >= 1 && T >= 0 && R >= 0 && (int64_t)nseg * T * R < (1LL << 31) && V > 0 && V < (1LL << 31),
+               "projce_forward: bad shape");
+  const long TR = (long)T * R, N = TR * nseg;
+  if (N == 0) return 0;
+  if (ce_fast_supported(E)) {
+    CVAE_TRY(launch_ce_fast_forward(final, W, b, tgt, pad, N, TR, E, (int)V, loss_row, lse, ws, s));
+  } else {
+    for (int g = 0; g < nseg; ++g)
+      CVAE_TRY(launch_projce_forward(final + g * TR * E, W, b, tgt, pad, (int)TR, E, (int)V, loss_row + g * TR,
+                                     lse + g * TR, ws, s));
+  }
+  if (sent)
+    for (int g = 0; g < nseg; ++g) CVAE_TRY(launch_sum_time(loss_row + g * TR, T, R, sent + (long)g * R, s));
   return 0;
 }
 
-int64_t cvae_projce_backward_workspace(int64_t N, int64_t V) {
+int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {
+  if (ce_fast_supported((int)E)) return ce_fast_bwd_workspace_floats(N, (int)V);
   return projce_bwd_workspace_floats((int)N, (int)V) + N;   // + broadcast of gsent over time
 }
 
 int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                         const float* lse, const float* gsent, int T, int R, int E, int64_t V, float* dfinal,
-                         float* dW, float* db, float* ws, void* stream) {
+                         const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                         float* dfinal, float* dW, float* db, float* ws, void* stream) {
   hipStream_t s = S(stream);
-  CVAE_REQUIRE(T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V < (1LL << 31), "projce_backward: bad shape");
+  CVAE_REQUIRE(nseg >= 1 && T >= 0 && R >= 0 && (int64_t)nseg * T * R < (1LL << 31) && V > 0 && V < (1LL << 31),
+               "projce_backward: bad shape");
   CVAE_REQUIRE(gsent && ws && dW && db, "projce_backward: null operand");
-  const int N = T * R;
-  float* grow = ws;
-  CVAE_TRY(launch_bcast_time(gsent, T, R, grow, s));
+  const long TR = (long)T * R, N = TR * nseg;
+  if (ce_fast_supported(E))
+    return launch_ce_fast_backward(final, W, b, tgt, pad, lse, gsent, N, TR, R, E, (int)V, dfinal, dW, db, ws, s);
   CVAE_TRY(check_hip(hipMemsetAsync(dW, 0, (size_t)V * E * sizeof(float), s), "dW memset"));
   CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)V * sizeof(float), s), "db memset"));
-  return launch_projce_backward(final, W, b, tgt, pad, lse, grow, N, E, (int)V, dfinal, dW, db, ws + N, s);
+  for (int g = 0; g < nseg; ++g) {
+    float* grow = ws;
+    CVAE_TRY(launch_bcast_time(gsent + (long)g * R, T, R, grow, s));
+    CVAE_TRY(launch_projce_backward(final + g * TR * E, W, b, tgt, pad, lse + g * TR, grow, (int)TR, E, (int)V,
+                                    dfinal + g * TR * E, dW, db, ws + TR, s));
+  }
+  return 0;
 }
 
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream) {

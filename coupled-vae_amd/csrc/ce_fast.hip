@@ -1,0 +1,658 @@
+// Hidden->vocab projection + softmax cross-entropy for E <= 200 (every shipped config has
+// emb_dim = 200): the hot kernels of both the training step and the IW-NLL evaluation.
+// Reference: ToVocab + SeqLoss, CV/Modules/vae_couple.py:119, CV/Modules/Losses/SeqLoss.py:36-44.
+//
+// What is different from a dense (N,V) logits GEMM:
+//  * Padding rows (target == pad) contribute neither loss nor gradient.  A scan builds the
+//    compact list of live rows on the device (no host sync); every kernel below works on that
+//    list and reads the live count from device memory, so ~half the rows of a Yelp batch are
+//    never multiplied at all.
+//  * ce_core_kernel is persistent (2 blocks per CU).  A block takes (128 live rows) x (a range
+//    of 32-wide vocab tiles) work items; the split of the vocabulary is chosen on the device
+//    from the live count so that the items fill the chip.  The 128 rows stay in REGISTERS for
+//    the whole item (each lane holds its row's K values, laid out as v_mfma_f32_32x32x2_f32
+//    B-fragments); only W tiles stream through LDS, double buffered, one barrier per tile.
+//  * The product is formed transposed, S^T = W_tile . X^T: a lane then owns one ROW and 16 of
+//    the tile's 32 vocab columns, so the online softmax state is two registers per lane and the
+//    gradient tile leaves the accumulators as four 16-byte stores per lane.
+//  * forward  (GRAD = false): per-(row, split) running (max, sum-exp) + target logit; a
+//    combine kernel merges the splits and scatters loss / lse to the original rows.
+//  * backward (GRAD = true): the same core writes P = coef * (softmax - onehot) for a chunk of
+//    live rows; gemm224_kernel then forms dX = P W (rows scattered back through the list) and
+//    [dW | db] += P^T [X | 1] (X rows gathered through the list) with exact-fp32 MFMA, split-K.
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace cvae {
+
+constexpr int CE_ROWS = 128;   // live rows per work item (4 waves x 32)
+constexpr int CE_TN = 32;      // vocab columns per tile
+constexpr int CE_LDW = 204;    // LDS row stride of a W tile: 200 k-values, bias at column 200; 204/4 odd -> b128 reads conflict-free
+constexpr int CE_BIAS_COL = 200;
+
+// ------------------------------------------------------------------------------------------
+// live-row list
+__global__ __launch_bounds__(1024) void ce_rows_count_kernel(int N, int TR, const int64_t* __restrict__ tgt,
+                                                             int64_t pad, int* __restrict__ counts,
+                                                             float* __restrict__ loss, float* __restrict__ lse,
+                                                             float* __restrict__ tl) {
+  __shared__ int wc[16];
+  const int n = blockIdx.x * 1024 + threadIdx.x;
+  const bool live = n < N && tgt[n % TR] != pad;
+  if (n < N) {
+    if (!live) {
+      if (loss) loss[n] = 0.f;
+      if (lse) lse[n] = 0.f;
+    }
+    if (tl) tl[n] = 0.f;
+  }
+  const unsigned long long b = __ballot(live);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c += wc[i];
+    counts[blockIdx.x] = c;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ce_rows_write_kernel(int N, int TR, const int64_t* __restrict__ tgt,
+                                                             int64_t pad, const int* __restrict__ counts,
+                                                             int* __restrict__ rows, int* __restrict__ nlive) {
+  __shared__ int red[16];
+  __shared__ int wc[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 1024) part += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int n = blockIdx.x * 1024 + threadIdx.x;
+  const bool live = n < N && tgt[n % TR] != pad;
+  const unsigned long long b = __ballot(live);
+  if (lane == 0) {
+    red[wave] = part;
+    wc[wave] = __popcll(b);
+  }
+  __syncthreads();
+  int off = 0, woff = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    off += red[i];
+    if (i < wave) woff += wc[i];
+    total += wc[i];
+  }
+  if (live) rows[off + woff + __popcll(b & ((1ull << lane) - 1ull))] = n;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nlive = off + total;
+}
+
+// ------------------------------------------------------------------------------------------
+// vocabulary split chosen on the device (forward, combine and backward must agree on it)
+__device__ __forceinline__ int ce_pick_split(int rb, int ntiles, int cap, int nblk) {
+  int smax = cap < ntiles ? cap : ntiles;
+  if (smax < 1) smax = 1;
+  int best = 1;
+  float bc = 3.0e38f;
+  for (int s = 1; s <= smax; ++s) {
+    const int items = rb * s;
+    const int rounds = (items + nblk - 1) / nblk;
+    const float c = (float)rounds / (float)s + 0.002f * (float)s;   // small price per extra split (partials, X reloads)
+    if (c < bc) { bc = c; best = s; }
+  }
+  const int tps = (ntiles + best - 1) / best;
+  return (ntiles + tps - 1) / tps;        // no empty splits
+}
+
+struct CeArgs {
+  const float* X;        // [N,E] rows of the decoder output
+  const float* W;        // [V,E]
+  const float* bias;     // [V]
+  const int64_t* tgt;    // [TR] targets, shared by the N/TR segments
+  const int* rows;       // compact list of live rows
+  const int* nlive;      // device count
+  int N, TR, E, V, vec;
+  int cap;               // forward: splits the partial workspace holds
+  long pstride;          // forward: floats between split slots
+  float* pm; float* ps; float* tl;
+  // GRAD
+  const float* lse;      // [N]
+  const float* gsent;    // [(N/TR) * R]
+  int R;
+  float* P; long ldp;    // [rcount, ldp] chunk of the gradient w.r.t. the logits (live rows r0 ...)
+  int r0, rcount;
+};
+
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ src, int k, int K, int vec) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && k + 3 < K) {
+    r = *reinterpret_cast<const float4*>(src);
+  } else {
+    if (k + 0 < K) r.x = src[0];
+    if (k + 1 < K) r.y = src[1];
+    if (k + 2 < K) r.z = src[2];
+    if (k + 3 < K) r.w = src[3];
+  }
+  return r;
+}
+
+__device__ __forceinline__ void lse_merge2(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  const float a = (m == M) ? 1.f : expf(m - M);     // (m == M) also covers -inf == -inf
+  const float b = (m2 == M) ? 1.f : expf(m2 - M);
+  s = s * a + s2 * b;
+  m = M;
+}
+
+// NQ: K is covered by NQ groups of 8 (zero padded): E <= 8*NQ <= 200.
+template <int NQ, bool GRAD, bool EXACT>
+__global__ __launch_bounds__(256, 2) void ce_core_kernel(CeArgs p) {
+  __shared__ __attribute__((aligned(16))) float Wt[2][CE_TN * CE_LDW];
+  constexpr int F4ROW = 2 * NQ;                 // float4 per W row
+  constexpr int NF4 = CE_TN * F4ROW;            // float4 per tile
+  constexpr int NST = (NF4 + 255) / 256;        // staged float4 per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int nlive = *p.nlive;
+  int rbeg = 0, rend = nlive;
+  if (GRAD) {
+    rbeg = p.r0;
+    rend = min(nlive, p.r0 + p.rcount);
+  }
+  if (rend <= rbeg) return;
+  const int rb = (rend - rbeg + CE_ROWS - 1) / CE_ROWS;
+  const int ntiles = (p.V + CE_TN - 1) / CE_TN;
+  const int nsplit = ce_pick_split(rb, ntiles, p.cap, gridDim.x);
+  const int tps = (ntiles + nsplit - 1) / nsplit;
+
+  // exact K and 16-byte rows: no per-element guards anywhere (uniform branch)
+  constexpr bool exactk = EXACT;     // host guarantees: 16-byte aligned operands and E == 8 * NQ
+  float4 st[NST];
+  float bst = 0.f;
+  auto stage_load = [&](int tile) {
+    const int n0 = tile * CE_TN;
+    if constexpr (exactk) {
+      // the tile is one contiguous block of W: float4 number idx of it
+      const float4* src = reinterpret_cast<const float4*>(p.W + (long)n0 * p.E);
+      const int lim = min(NF4, (p.V - n0) * F4ROW);
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const int idx = tid + 256 * i;
+        st[i] = (idx < lim) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < NF4) {
+          const int row = idx / F4ROW, k = 4 * (idx % F4ROW);
+          const int vr = n0 + row;
+          if (vr < p.V) v = load4_guard(p.W + (long)vr * p.E + k, k, p.E, p.vec);
+        }
+        st[i] = v;
+      }
+    }
+    if (tid < CE_TN) bst = (n0 + tid < p.V) ? p.bias[n0 + tid] : -INFINITY;
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < NF4) {
+        const int row = idx / F4ROW, k = 4 * (idx % F4ROW);
+        *reinterpret_cast<float4*>(&Wt[buf][row * CE_LDW + k]) = st[i];
+      }
+    }
+    if (tid < CE_TN) Wt[buf][tid * CE_LDW + CE_BIAS_COL] = bst;
+  };
+
+  for (int item = blockIdx.x; item < rb * nsplit; item += gridDim.x) {
+    const int sp = item % nsplit, rbi = item / nsplit;
+    const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
+    const int ci = rbeg + rbi * CE_ROWS + wave * 32 + l31;     // index into the live list
+    const bool rv = ci < rend;
+    const int n = rv ? p.rows[ci] : 0;
+    // this lane's row as MFMA B-fragments: step (q, s) uses k = 8q + 4*lhi + s
+    float x[4 * NQ];
+    if constexpr (exactk) {
+      const float4* xr = reinterpret_cast<const float4*>(p.X + (long)n * p.E) + lhi;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 v = rv ? xr[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = 8 * q + 4 * lhi;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv) v = load4_guard(p.X + (long)n * p.E + k, k, p.E, p.vec);
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
+    }
+    int tg = -1;
+    if (rv) {
+      const int64_t t = p.tgt[n % p.TR];
+      if (t >= 0 && t < p.V) tg = (int)t;
+    }
+    float m = -INFINITY, s = 0.f, tlv = 0.f;
+    bool found = false;
+    float lse_r = 0.f, coef = 0.f;
+    float* prow = nullptr;
+    if (GRAD) {
+      if (rv) {
+        lse_r = p.lse[n];
+        coef = p.gsent[(n / p.TR) * p.R + n % p.R];
+      }
+      prow = p.P + (long)(ci - p.r0) * p.ldp;
+    }
+
+    stage_load(t0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const int buf = (t - t0) & 1;
+      const int n0 = t * CE_TN;
+      if (t + 1 < t1) stage_load(t + 1);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* wl = &Wt[buf][l31 * CE_LDW + 4 * lhi];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wl + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, x[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, x[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, x[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, x[4 * q + 3], acc, 0, 0, 0);
+      }
+      // acc[r] = logit(row = this lane's, vocab column n0 + j), j = (r & 3) + 8 * (r >> 2) + 4 * lhi
+      float xv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        xv[r] = acc[r] + Wt[buf][j * CE_LDW + CE_BIAS_COL];     // -inf beyond V
+      }
+      if (!GRAD) {
+        float mx = xv[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, xv[r]);
+        const float mn = fmaxf(m, mx);
+        const float mref = (mn == -INFINITY) ? 0.f : mn;
+        float sum = s * __expf(m - mref);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __expf(xv[r] - mref);
+        s = sum;
+        m = mn;
+        const int jt = tg - n0 - 4 * lhi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (jt == (r & 3) + 8 * (r >> 2)) { tlv = xv[r]; found = true; }
+      } else {
+        const int jt = tg - n0 - 4 * lhi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            o[i] = coef * (__expf(xv[r] - lse_r) - ((jt == i + 8 * g) ? 1.f : 0.f));
+          }
+          if (rv) *reinterpret_cast<float4*>(prow + n0 + 8 * g + 4 * lhi) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      if (t + 1 < t1) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+    if (!GRAD) {
+      const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
+      lse_merge2(m, s, m2, s2);
+      if (rv) {
+        if (lhi == 0) {
+          p.pm[(long)sp * p.pstride + ci] = m;
+          p.ps[(long)sp * p.pstride + ci] = s;
+        }
+        if (found) p.tl[ci] = tlv;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, float* __restrict__ loss,
+                                                          float* __restrict__ lse) {
+  const int nlive = *p.nlive;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlive) return;
+  const int rb = (nlive + CE_ROWS - 1) / CE_ROWS;
+  const int nsplit = ce_pick_split(rb, (p.V + CE_TN - 1) / CE_TN, p.cap, nblk);
+  float m = -INFINITY, s = 0.f;
+  for (int k = 0; k < nsplit; ++k) lse_merge2(m, s, p.pm[(long)k * p.pstride + i], p.ps[(long)k * p.pstride + i]);
+  const float l = m + logf(s);
+  const int n = p.rows[i];
+  lse[n] = l;
+  loss[n] = l - p.tl[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// C[M, N<=224] += A[M,K] . B[K,N]  (split-K, atomic accumulate), for the two contractions that
+// consume P and for every other "200-wide" product of the training step.
+//   AKC = true : A stored [m][k] (k contiguous)  -> dX   = P   . W
+//   AKC = false: A stored [k][m] (m contiguous)  -> dW  += P^T . X
+// Block 128 x 224 (4 waves x 32 rows x 7 column fragments of v_mfma_f32_32x32x2_f32), BK = 16,
+// double-buffered LDS, one barrier per chunk.  B is always [k][n]; its fragments are read with
+// one b128 + one b64 + one b32 per MFMA step (column permutation resolved in the epilogue).
+constexpr int G2_BM = 128, G2_BN = 224, G2_BK = 16, G2_LDA = 20;
+
+struct G224Args {
+  const float* A; long lda;
+  const float* B; long ldb;
+  float* C; long ldc;
+  int M, N, K;            // N: real columns of B (N <= 220)
+  const int* nlive; int r0;
+  int dev_bound;          // 0: none; 1: M limited to nlive - r0; 2: K limited to nlive - r0
+  const int* rows;        // dev_bound 1: C row = rows[r0 + m]; dev_bound 2: B row = rows[r0 + k]
+  float* extra;           // optional [M]: extra[m] += sum_k A[m,k]  (a ones column appended to B)
+  int kchunk;
+  int vecA, vecB;
+};
+
+template <bool AKC>
+__global__ __launch_bounds__(256, 2) void gemm224_kernel(G224Args p) {
+  __shared__ __attribute__((aligned(16))) float As[2][AKC ? G2_BM * G2_LDA : G2_BK * G2_BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][G2_BK * G2_BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int Mlim = p.M, Klim = p.K;
+  if (p.dev_bound) {
+    int lim = *p.nlive - p.r0;
+    if (lim < 0) lim = 0;
+    if (p.dev_bound == 1) Mlim = min(Mlim, lim); else Klim = min(Klim, lim);
+  }
+  const int m0 = blockIdx.x * G2_BM;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(Klim, kbeg + p.kchunk);
+  if (m0 >= Mlim || kbeg >= kend) return;
+  const int nf4 = (p.N + 3) >> 2;                 // float4 per B row
+  const int ones_col = p.extra ? 4 * nf4 : -1;
+
+  // pad columns of B (never restaged): zero, except the ones column
+  for (int i = tid; i < 2 * G2_BK * G2_BN; i += 256) {
+    const int c = i % G2_BN;
+    if (c >= 4 * nf4) (&Bs[0][0])[i] = (c == ones_col) ? 1.f : 0.f;
+  }
+
+  // staging maps (fixed per thread)
+  int bkr[4], bc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    bkr[i] = (idx < G2_BK * nf4) ? idx / nf4 : -1;
+    bc[i] = 4 * (idx % nf4);
+  }
+  float4 sa[2], sb[4];
+  auto stage_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AKC) {
+        const int row = m0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+        if (row < Mlim && k < kend) v = load4_guard(p.A + (long)row * p.lda + k, k, kend, p.vecA);
+      } else {
+        const int k = k0 + (idx >> 5), m = m0 + 4 * (idx & 31);
+        if (k < kend && m < p.M) v = load4_guard(p.A + (long)k * p.lda + m, m, p.M, p.vecA);
+      }
+      sa[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = k0 + bkr[i];
+      if (bkr[i] >= 0 && k < kend) {
+        const long brow = (p.dev_bound == 2) ? (long)p.rows[p.r0 + k] : (long)k;
+        v = load4_guard(p.B + brow * p.ldb + bc[i], bc[i], p.N, p.vecB);
+      }
+      sb[i] = v;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      if (AKC) *reinterpret_cast<float4*>(&As[buf][(idx >> 2) * G2_LDA + 4 * (idx & 3)]) = sa[i];
+      else *reinterpret_cast<float4*>(&As[buf][(idx >> 5) * G2_BM + 4 * (idx & 31)]) = sa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (bkr[i] >= 0) *reinterpret_cast<float4*>(&Bs[buf][bkr[i] * G2_BN + bc[i]]) = sb[i];
+  };
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  stage_load(kbeg);
+  __syncthreads();                 // pad-column init visible before anyone reads
+  stage_store(0);
+  __syncthreads();
+  const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage_load(kbeg + (kt + 1) * G2_BK);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float a[4];
+      if (AKC) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][(wave * 32 + l31) * G2_LDA + 8 * q + 4 * lhi]);
+        a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = As[buf][(8 * q + 4 * lhi + s) * G2_BM + wave * 32 + l31];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* br = &Bs[buf][(8 * q + 4 * lhi + s) * G2_BN];
+        const float4 b0 = *reinterpret_cast<const float4*>(br + 4 * l31);
+        const float2 b1 = *reinterpret_cast<const float2*>(br + 128 + 2 * l31);
+        const float b2 = br[192 + l31];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.w, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1.x, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1.y, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b2, acc[6], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[j][r] -> row = m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lhi ; column by fragment
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    if (row >= Mlim) continue;
+    const long crow = (p.dev_bound == 1) ? (long)p.rows[p.r0 + row] : (long)row;
+    float* c = p.C + crow * p.ldc;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int col = (j < 4) ? 4 * l31 + j : (j < 6) ? 128 + 2 * l31 + (j - 4) : 192 + l31;
+      if (col < p.N) atomicAdd(c + col, acc[j][r]);
+      else if (col == ones_col) atomicAdd(p.extra + row, acc[j][r]);
+    }
+  }
+}
+
+int launch_gemm224(bool akc, G224Args a, hipStream_t s) {
+  CVAE_REQUIRE(a.N > 0 && a.N <= 220, "gemm224: N=%d out of range", a.N);
+  if (a.M <= 0 || a.K <= 0) return 0;
+  const int mtiles = cdiv(a.M, G2_BM);
+  int ksplit = cdiv(512, mtiles);
+  const int maxs = a.K / (8 * G2_BK) > 0 ? a.K / (8 * G2_BK) : 1;
+  if (ksplit > maxs) ksplit = maxs;
+  a.kchunk = cdiv(cdiv(a.K, ksplit), G2_BK) * G2_BK;
+  ksplit = cdiv(a.K, a.kchunk);
+  a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
+  a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
+  dim3 grid(mtiles, 1, ksplit);
+  ProfScope prof(PK_GEMM_TILED, s, 2.0 * a.M * a.N * a.K);
+  if (akc) hipLaunchKernelGGL(gemm224_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm224_kernel<false>, grid, dim3(256), 0, s, a);
+  CVAE_LAUNCH_CHECK("gemm224_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+static int ce_grid_blocks() {
+  static int nblk = 0;
+  if (!nblk) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    nblk = 2 * cus;
+  }
+  return nblk;
+}
+
+static int ce_cap(long N, int V) {
+  const long rb = (N + CE_ROWS - 1) / CE_ROWS;
+  long cap = (2L * ce_grid_blocks() + rb - 1) / rb;
+  if (cap > 64) cap = 64;
+  if (cap < 1) cap = 1;
+  const int ntiles = cdiv(V, CE_TN);
+  return (int)(cap < ntiles ? cap : ntiles);
+}
+
+bool ce_fast_supported(int E) { return E >= 1 && E <= 200; }
+
+// workspace (floats): rows[N] | counts | nlive | tl[N] | pm[cap*N] | ps[cap*N]
+static long ce_counts_slots(long N) { return (N + 1023) / 1024 + 8; }
+long ce_fast_workspace_floats(long N, int V) {
+  return N + ce_counts_slots(N) + N + 2L * ce_cap(N, V) * N + 16;
+}
+
+static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* rows, int* counts, int* nlive,
+                       float* loss, float* lse, float* tl, hipStream_t s) {
+  const int nb = cdiv(N, 1024);
+  hipLaunchKernelGGL(ce_rows_count_kernel, dim3(nb), dim3(1024), 0, s, (int)N, (int)TR, tgt, pad, counts, loss, lse, tl);
+  CVAE_LAUNCH_CHECK("ce_rows_count_kernel");
+  hipLaunchKernelGGL(ce_rows_write_kernel, dim3(nb), dim3(1024), 0, s, (int)N, (int)TR, tgt, pad, counts, rows, nlive);
+  CVAE_LAUNCH_CHECK("ce_rows_write_kernel");
+  return 0;
+}
+
+template <bool GRAD>
+static int launch_core(const CeArgs& a, hipStream_t s) {
+  const dim3 grid(ce_grid_blocks()), block(256);
+  const int nq = (a.E + 7) / 8;
+#define CE_CASE(NQ_)                                                                          \
+  do {                                                                                        \
+    if (a.vec && a.E == 8 * NQ_) hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, true>), grid, block, 0, s, a);  \
+    else hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, false>), grid, block, 0, s, a);        \
+  } while (0)
+  if (nq <= 2) CE_CASE(2);
+  else if (nq <= 4) CE_CASE(4);
+  else if (nq <= 8) CE_CASE(8);
+  else if (nq <= 13) CE_CASE(13);
+  else CE_CASE(25);
+#undef CE_CASE
+  CVAE_LAUNCH_CHECK("ce_core_kernel");
+  return 0;
+}
+
+// X [nseg*TR, E]; tgt [TR]; loss, lse [nseg*TR]
+int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, hipStream_t s) {
+  CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && N % TR == 0 && N < (1L << 31), "ce_forward: bad shape");
+  if (N == 0) return 0;
+  CVAE_REQUIRE(X && W && bias && tgt && loss && lse && ws, "ce_forward: null operand");
+  const int cap = ce_cap(N, V);
+  int* rows = reinterpret_cast<int*>(ws);
+  int* counts = rows + N;
+  int* nlive = counts + ce_counts_slots(N) - 4;
+  float* tl = ws + N + ce_counts_slots(N);
+  CeArgs a = {};
+  a.X = X; a.W = W; a.bias = bias; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
+  a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
+  a.vec = aligned16(X) && aligned16(W) && (E % 4 == 0);
+  a.cap = cap; a.pstride = N; a.tl = tl; a.pm = tl + N; a.ps = a.pm + (long)cap * N;
+  CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, loss, lse, tl, s));
+  {
+    ProfScope prof(PK_CE_FWD, s, 2.0 * N * E * V);
+    CVAE_TRY(launch_core<false>(a, s));
+  }
+  hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, ce_grid_blocks(), loss, lse);
+  CVAE_LAUNCH_CHECK("ce_combine2_kernel");
+  return 0;
+}
+
+static long ce_ldp(int V) { return (long)cdiv(V, CE_TN) * CE_TN; }
+static long ce_chunk_rows(long N, int V) {
+  static long mb = -1;
+  if (mb < 0) {
+    const char* e = getenv("CVAE_CE_CHUNK_MB");
+    mb = e ? atol(e) : 512;
+    if (mb < 1) mb = 1;
+  }
+  long ch = (mb << 20) / (ce_ldp(V) * 4);
+  ch = ch / CE_ROWS * CE_ROWS;
+  if (ch < CE_ROWS) ch = CE_ROWS;
+  const long nr = (N + CE_ROWS - 1) / CE_ROWS * CE_ROWS;
+  return ch < nr ? ch : nr;
+}
+// workspace (floats): rows[N] | counts | nlive | P[chunk * ldp]
+long ce_fast_bwd_workspace_floats(long N, int V) {
+  return N + ce_counts_slots(N) + 16 + ce_chunk_rows(N, V) * ce_ldp(V);
+}
+
+// dX [N,E] overwritten; dW [V,E], db [V] overwritten.
+int launch_ce_fast_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                            const float* lse, const float* gsent, long N, long TR, int R, int E, int V,
+                            float* dX, float* dW, float* db, float* ws, hipStream_t s) {
+  CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && R > 0 && TR % R == 0 && N % TR == 0 && N < (1L << 31),
+               "ce_backward: bad shape");
+  CVAE_TRY(check_hip(hipMemsetAsync(dW, 0, (size_t)V * E * sizeof(float), s), "dW memset"));
+  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)V * sizeof(float), s), "db memset"));
+  if (N == 0) return 0;
+  CVAE_REQUIRE(X && W && bias && tgt && lse && gsent && dX && dW && db && ws, "ce_backward: null operand");
+  CVAE_TRY(check_hip(hipMemsetAsync(dX, 0, (size_t)N * E * sizeof(float), s), "dX memset"));
+  int* rows = reinterpret_cast<int*>(ws);
+  int* counts = rows + N;
+  int* nlive = counts + ce_counts_slots(N) - 4;
+  float* P = ws + N + ce_counts_slots(N) + 16;
+  P = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(P) + 15) & ~(uintptr_t)15);
+  const long ldp = ce_ldp(V), CH = ce_chunk_rows(N, V);
+  CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, nullptr, nullptr, nullptr, s));
+  CeArgs a = {};
+  a.X = X; a.W = W; a.bias = bias; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
+  a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
+  a.vec = aligned16(X) && aligned16(W) && (E % 4 == 0);
+  a.cap = 64; a.lse = lse; a.gsent = gsent; a.R = R; a.P = P; a.ldp = ldp;
+  for (long r0 = 0; r0 < N; r0 += CH) {
+    const int rc = (int)((N - r0) < CH ? (N - r0) : CH);
+    a.r0 = (int)r0; a.rcount = rc;
+    {
+      ProfScope prof(PK_CE_FWD, s, 2.0 * rc * E * V);
+      CVAE_TRY(launch_core<true>(a, s));
+    }
+    G224Args gx = {};      // dX[rows[r0+m], :] += P[m, :] . W
+    gx.A = P; gx.lda = ldp; gx.B = W; gx.ldb = E; gx.C = dX; gx.ldc = E;
+    gx.M = rc; gx.N = E; gx.K = V; gx.nlive = nlive; gx.r0 = (int)r0; gx.dev_bound = 1; gx.rows = rows;
+    CVAE_TRY(launch_gemm224(true, gx, s));
+    G224Args gw = {};      // [dW | db] += P^T . [X[rows[r0+k], :] | 1]
+    gw.A = P; gw.lda = ldp; gw.B = X; gw.ldb = E; gw.C = dW; gw.ldc = E;
+    gw.M = V; gw.N = E; gw.K = rc; gw.nlive = nlive; gw.r0 = (int)r0; gw.dev_bound = 2; gw.rows = rows;
+    gw.extra = db;
+    CVAE_TRY(launch_gemm224(false, gw, s));
+  }
+  return 0;
+}
+
+}  // namespace cvae

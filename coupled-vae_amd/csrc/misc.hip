@@ -190,16 +190,28 @@ int launch_axpy(long n, const float* x, float a, float* y, hipStream_t s) {
   return 0;
 }
 
-// out[r] = sum_t x[t*R + r]
-__global__ void sum_time_kernel(int T, int R, const float* __restrict__ x, float* __restrict__ out) {
-  IDX1D(R);
+// out[r] = sum_t x[t*R + r]: a block owns 64 columns; its 16 waves take the time steps
+// round-robin (fixed summation order: deterministic).
+__global__ __launch_bounds__(1024) void sum_time_kernel(int T, int R, const float* __restrict__ x,
+                                                        float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int t = 0; t < T; ++t) acc += x[(long)t * R + idx];
-  out[idx] = acc;
+  if (r < R)
+    for (int t = wave; t < T; t += 16) acc += x[(long)t * R + r];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && r < R) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += part[w][lane];
+    out[r] = tot;
+  }
 }
 int launch_sum_time(const float* x, int T, int R, float* out, hipStream_t s) {
   if (R == 0) return 0;
-  hipLaunchKernelGGL(sum_time_kernel, GRID1D(R), 0, s, T, R, x, out);
+  hipLaunchKernelGGL(sum_time_kernel, dim3(cdiv(R, 64)), dim3(1024), 0, s, T, R, x, out);
   CVAE_LAUNCH_CHECK("sum_time_kernel");
   return 0;
 }

@@ -52,4 +52,14 @@ int launch_projce_backward(const float* X, const float* W, const float* bias, co
                            float* db, float* ws, hipStream_t s);
 int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStream_t s);
 
+// ce_fast.hip (E <= 200): live-row compaction + register-resident rows + 224-wide split-K GEMMs
+bool ce_fast_supported(int E);
+long ce_fast_workspace_floats(long N, int V);
+int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, hipStream_t s);
+long ce_fast_bwd_workspace_floats(long N, int V);
+int launch_ce_fast_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
+                            const float* lse, const float* gsent, long N, long TR, int R, int E, int V,
+                            float* dX, float* dW, float* db, float* ws, hipStream_t s);
+
 }  // namespace cvae

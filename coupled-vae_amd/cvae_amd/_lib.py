@@ -37,10 +37,10 @@ SIGNATURES = {
     'cvae_decoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     'cvae_decoder_forward_n': [I, I, I, I, I, I, L] + [P] * 14,
     'cvae_decoder_backward_n': [I, I, I, I, I, I, L] + [P] * 16,
-    'cvae_projce_workspace': [L, L],
-    'cvae_projce_forward': [P, P, P, P, L, I, I, I, L, P, P, P, P, P],
-    'cvae_projce_backward_workspace': [L, L],
-    'cvae_projce_backward': [P, P, P, P, L, P, P, I, I, I, L, P, P, P, P, P],
+    'cvae_projce_workspace': [L, L, L],
+    'cvae_projce_forward': [P, P, P, P, L, I, I, I, I, L, P, P, P, P, P],
+    'cvae_projce_backward_workspace': [L, L, L],
+    'cvae_projce_backward': [P, P, P, P, L, P, P, I, I, I, I, L, P, P, P, P, P],
     'cvae_targets_time_major': [P, I, I, I, P, P],
     'cvae_logits': [P, P, P, I, I, I, L, P, P, P],
     'cvae_reparam_forward': [P, P, P, I, I, I, P, P],

@@ -295,9 +295,9 @@ class ProjCEFn(torch.autograd.Function):
         V = W.shape[0]
         N = T * R
         loss_row, lse, sent = _f((N,), final), _f((N,), final), _f((R,), final)
-        ws = _f((query('cvae_projce_workspace', N, V),), final)
-        call('cvae_projce_forward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, T, R, E, V, ptr(loss_row), ptr(lse),
-             ptr(sent), ptr(ws), stream())
+        ws = _f((query('cvae_projce_workspace', N, E, V),), final)
+        call('cvae_projce_forward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, 1, T, R, E, V, ptr(loss_row),
+             ptr(lse), ptr(sent), ptr(ws), stream())
         ctx.pad = pad
         ctx.save_for_backward(final, W, b, tgt_tm, lse)
         return sent
@@ -309,9 +309,9 @@ class ProjCEFn(torch.autograd.Function):
         V = W.shape[0]
         gsent = _c(gsent)
         dfinal, dW, db = torch.empty_like(final), torch.empty_like(W), torch.empty_like(b)
-        ws = _f((query('cvae_projce_backward_workspace', T * R, V),), final)
-        call('cvae_projce_backward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent), T, R, E, V,
-             ptr(dfinal), ptr(dW), ptr(db), ptr(ws), stream())
+        ws = _f((query('cvae_projce_backward_workspace', T * R, E, V),), final)
+        call('cvae_projce_backward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent), 1, T, R, E,
+             V, ptr(dfinal), ptr(dW), ptr(db), ptr(ws), stream())
         return dfinal, dW, db, None, None
 
 

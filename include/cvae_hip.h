@@ -115,20 +115,23 @@ int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64
                             float* const* scratch, void* stream);
 
 /* ---- a7 tail + a8: ToVocab + SeqLoss(keep_batch=True) (Modules/vae_couple.py:119,
- * Modules/Losses/SeqLoss.py:36-44), fused: logits are never materialised.
- * final[T*R,E] (time-major rows n = t*R + r), W[V,E], b[V], tgt[T*R] (time-major targets),
- * -> loss_row[T*R] (0 where tgt == pad), lse[T*R], sent[R] = sum over t.
- * ws: cvae_projce_workspace(T*R, V) floats. */
-int64_t cvae_projce_workspace(int64_t N, int64_t V);
+ * Modules/Losses/SeqLoss.py:36-44), fused: logits are never materialised, and rows whose target
+ * is `pad` (loss 0, gradient 0 in the reference) are never multiplied.
+ * final[nseg][T*R, E]: nseg stacked decoder outputs that share the targets (the decoder and its
+ * coupled twin, vae_couple.py:371-376), rows time-major n = t*R + r inside a segment;
+ * W[V,E], b[V], tgt[T*R] (time-major targets)
+ * -> loss_row[nseg*T*R] (0 where tgt == pad), lse[nseg*T*R], sent[nseg*R] = sum over t.
+ * ws: cvae_projce_workspace(nseg*T*R, E, V) floats. */
+int64_t cvae_projce_workspace(int64_t N, int64_t E, int64_t V);
 int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                        int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent, float* ws,
-                        void* stream);
-/* gsent[R] = dL/dsent.  dfinal[T*R,E] overwritten; dW[V,E], db[V] overwritten.
- * ws: cvae_projce_backward_workspace(T*R, V) floats. */
-int64_t cvae_projce_backward_workspace(int64_t N, int64_t V);
+                        int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                        float* ws, void* stream);
+/* gsent[nseg*R] = dL/dsent.  dfinal[nseg*T*R,E], dW[V,E], db[V] are overwritten.
+ * ws: cvae_projce_backward_workspace(nseg*T*R, E, V) floats. */
+int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V);
 int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                         const float* lse, const float* gsent, int T, int R, int E, int64_t V, float* dfinal,
-                         float* dW, float* db, float* ws, void* stream);
+                         const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                         float* dfinal, float* dW, float* db, float* ws, void* stream);
 /* tgt_tm[t*R + r] = eos[(r % B)*T + t]: time-major targets for R = n*B rows. */
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream);
 /* Materialise logits[B,T,V] (batch-major, as the reference returns them) for callers that

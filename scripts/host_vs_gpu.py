@@ -6,7 +6,9 @@ import torch
 from cvae_amd import _lib, data, harness
 dev = torch.device('cuda:0'); _lib.init(0)
 cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
-shape = data.SHAPES['yelp']
+shape = dict(data.SHAPES['yelp'])
+if len(sys.argv) > 2:
+    shape['V'] = int(sys.argv[2])       # smaller vocab = less GPU work at equal launch count
 hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'])
 tr = harness.Trainer(hp, dev, seed=0); tr.iter_num = 20000
 B = 32; n = 13

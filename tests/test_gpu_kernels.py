@@ -198,7 +198,10 @@ def test_decoder_forward_backward(dev, cell, shape):
         assert rel(got_e, ref_e) < 2e-5, n_rep
 
 
-@pytest.mark.parametrize('shape', [(7, 5, 16, 50), (40, 32, 200, 10002), (3, 700, 200, 20001)])
+# E = 16/32/200: exact-K register path; 30/104: zero-padded K; 208: generic fallback (E > 200);
+# V off the 32-column tile; R*T above and below one 128-row item
+@pytest.mark.parametrize('shape', [(7, 5, 16, 50), (40, 32, 200, 10002), (3, 700, 200, 20001), (6, 9, 30, 77),
+                                   (5, 33, 104, 333), (9, 40, 32, 160), (4, 6, 208, 100)])
 def test_projce_forward_backward(dev, shape):
     from cvae_amd import ops
     T, R, E, V = shape
