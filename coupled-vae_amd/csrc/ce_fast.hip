@@ -335,195 +335,10 @@ __global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, fl
 }
 
 // ------------------------------------------------------------------------------------------
-// C[M, N<=224] += A[M,K] . B[K,N]  (split-K, atomic accumulate), for the two contractions that
-// consume P and for every other "200-wide" product of the training step.
-//   AKC = true : A stored [m][k] (k contiguous)  -> dX   = P   . W
-//   AKC = false: A stored [k][m] (m contiguous)  -> dW  += P^T . X
-// Block 128 x 224 (4 waves x 32 rows x 7 column fragments of v_mfma_f32_32x32x2_f32), BK = 16,
-// double-buffered LDS, one barrier per chunk.  B is always [k][n]; its fragments are read with
-// one b128 + one b64 + one b32 per MFMA step (column permutation resolved in the epilogue).
-constexpr int G2_BM = 128, G2_BN = 224, G2_BK = 16, G2_LDA = 20;
-
-struct G224Args {
-  const float* A; long lda;
-  const float* B; long ldb;
-  float* C; long ldc;
-  int M, N, K;            // N: real columns of B (N <= 220)
-  const int* nlive; int r0;
-  int dev_bound;          // 0: none; 1: M limited to nlive - r0; 2: K limited to nlive - r0
-  const int* rows;        // dev_bound 1: C row = rows[r0 + m]; dev_bound 2: B row = rows[r0 + k]
-  float* extra;           // optional [M]: extra[m] += sum_k A[m,k]  (a ones column appended to B)
-  int kchunk;
-  int vecA, vecB;
-};
-
-template <bool AKC>
-__global__ __launch_bounds__(256, 2) void gemm224_kernel(G224Args p) {
-  __shared__ __attribute__((aligned(16))) float As[2][AKC ? G2_BM * G2_LDA : G2_BK * G2_BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][G2_BK * G2_BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  int Mlim = p.M, Klim = p.K;
-  if (p.dev_bound) {
-    int lim = *p.nlive - p.r0;
-    if (lim < 0) lim = 0;
-    if (p.dev_bound == 1) Mlim = min(Mlim, lim); else Klim = min(Klim, lim);
-  }
-  const int m0 = blockIdx.x * G2_BM;
-  const int kbeg = blockIdx.z * p.kchunk;
-  const int kend = min(Klim, kbeg + p.kchunk);
-  if (m0 >= Mlim || kbeg >= kend) return;
-  const int nf4 = (p.N + 3) >> 2;                 // float4 per B row
-  const int ones_col = p.extra ? 4 * nf4 : -1;
-
-  // pad columns of B (never restaged): zero, except the ones column
-  for (int i = tid; i < 2 * G2_BK * G2_BN; i += 256) {
-    const int c = i % G2_BN;
-    if (c >= 4 * nf4) (&Bs[0][0])[i] = (c == ones_col) ? 1.f : 0.f;
-  }
-
-  // staging maps (fixed per thread)
-  int bkr[4], bc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i;
-    bkr[i] = (idx < G2_BK * nf4) ? idx / nf4 : -1;
-    bc[i] = 4 * (idx % nf4);
-  }
-  float4 sa[2], sb[4];
-  auto stage_load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (AKC) {
-        const int row = m0 + (idx >> 2), k = k0 + 4 * (idx & 3);
-        if (row < Mlim && k < kend) v = load4_guard(p.A + (long)row * p.lda + k, k, kend, p.vecA);
-      } else {
-        const int k = k0 + (idx >> 5), m = m0 + 4 * (idx & 31);
-        if (k < kend && m < p.M) v = load4_guard(p.A + (long)k * p.lda + m, m, p.M, p.vecA);
-      }
-      sa[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int k = k0 + bkr[i];
-      if (bkr[i] >= 0 && k < kend) {
-        const long brow = (p.dev_bound == 2) ? (long)p.rows[p.r0 + k] : (long)k;
-        v = load4_guard(p.B + brow * p.ldb + bc[i], bc[i], p.N, p.vecB);
-      }
-      sb[i] = v;
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      if (AKC) *reinterpret_cast<float4*>(&As[buf][(idx >> 2) * G2_LDA + 4 * (idx & 3)]) = sa[i];
-      else *reinterpret_cast<float4*>(&As[buf][(idx >> 5) * G2_BM + 4 * (idx & 31)]) = sa[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (bkr[i] >= 0) *reinterpret_cast<float4*>(&Bs[buf][bkr[i] * G2_BN + bc[i]]) = sb[i];
-  };
-
-  f32x16 acc[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  stage_load(kbeg);
-  __syncthreads();                 // pad-column init visible before anyone reads
-  stage_store(0);
-  __syncthreads();
-  const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage_load(kbeg + (kt + 1) * G2_BK);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float a[4];
-      if (AKC) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][(wave * 32 + l31) * G2_LDA + 8 * q + 4 * lhi]);
-        a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = As[buf][(8 * q + 4 * lhi + s) * G2_BM + wave * 32 + l31];
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float* br = &Bs[buf][(8 * q + 4 * lhi + s) * G2_BN];
-        const float4 b0 = *reinterpret_cast<const float4*>(br + 4 * l31);
-        const float2 b1 = *reinterpret_cast<const float2*>(br + 128 + 2 * l31);
-        const float b2 = br[192 + l31];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0.w, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1.x, acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1.y, acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b2, acc[6], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nk) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-
-  // epilogue: acc[j][r] -> row = m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lhi ; column by fragment
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-    if (row >= Mlim) continue;
-    const long crow = (p.dev_bound == 1) ? (long)p.rows[p.r0 + row] : (long)row;
-    float* c = p.C + crow * p.ldc;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int col = (j < 4) ? 4 * l31 + j : (j < 6) ? 128 + 2 * l31 + (j - 4) : 192 + l31;
-      if (col < p.N) atomicAdd(c + col, acc[j][r]);
-      else if (col == ones_col) atomicAdd(p.extra + row, acc[j][r]);
-    }
-  }
-}
-
-int launch_gemm224(bool akc, G224Args a, hipStream_t s) {
-  CVAE_REQUIRE(a.N > 0 && a.N <= 220, "gemm224: N=%d out of range", a.N);
-  if (a.M <= 0 || a.K <= 0) return 0;
-  const int mtiles = cdiv(a.M, G2_BM);
-  int ksplit = cdiv(512, mtiles);
-  const int maxs = a.K / (8 * G2_BK) > 0 ? a.K / (8 * G2_BK) : 1;
-  if (ksplit > maxs) ksplit = maxs;
-  a.kchunk = cdiv(cdiv(a.K, ksplit), G2_BK) * G2_BK;
-  ksplit = cdiv(a.K, a.kchunk);
-  a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
-  a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
-  dim3 grid(mtiles, 1, ksplit);
-  ProfScope prof(PK_GEMM_TILED, s, 2.0 * a.M * a.N * a.K);
-  if (akc) hipLaunchKernelGGL(gemm224_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gemm224_kernel<false>, grid, dim3(256), 0, s, a);
-  CVAE_LAUNCH_CHECK("gemm224_kernel");
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------
 // host side
-static int ce_grid_blocks() {
-  static int nblk = 0;
-  if (!nblk) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    }
-    nblk = 2 * cus;
-  }
-  return nblk;
-}
-
 static int ce_cap(long N, int V) {
   const long rb = (N + CE_ROWS - 1) / CE_ROWS;
-  long cap = (2L * ce_grid_blocks() + rb - 1) / rb;
+  long cap = (2L * persistent_grid_blocks() + rb - 1) / rb;
   if (cap > 64) cap = 64;
   if (cap < 1) cap = 1;
   const int ntiles = cdiv(V, CE_TN);
@@ -550,7 +365,7 @@ static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* ro
 
 template <bool GRAD>
 static int launch_core(const CeArgs& a, hipStream_t s) {
-  const dim3 grid(ce_grid_blocks()), block(256);
+  const dim3 grid(persistent_grid_blocks()), block(256);
   const int nq = (a.E + 7) / 8;
 #define CE_CASE(NQ_)                                                                          \
   do {                                                                                        \
@@ -588,7 +403,7 @@ int launch_ce_fast_forward(const float* X, const float* W, const float* bias, co
     ProfScope prof(PK_CE_FWD, s, 2.0 * N * E * V);
     CVAE_TRY(launch_core<false>(a, s));
   }
-  hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, ce_grid_blocks(), loss, lse);
+  hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, persistent_grid_blocks(), loss, lse);
   CVAE_LAUNCH_CHECK("ce_combine2_kernel");
   return 0;
 }
@@ -607,9 +422,9 @@ static long ce_chunk_rows(long N, int V) {
   const long nr = (N + CE_ROWS - 1) / CE_ROWS * CE_ROWS;
   return ch < nr ? ch : nr;
 }
-// workspace (floats): rows[N] | counts | nlive | P[chunk * ldp]
+// workspace (floats): rows[N] | counts | nlive | P[chunk * ldp] | split-K slabs
 long ce_fast_bwd_workspace_floats(long N, int V) {
-  return N + ce_counts_slots(N) + 16 + ce_chunk_rows(N, V) * ce_ldp(V);
+  return N + ce_counts_slots(N) + 16 + ce_chunk_rows(N, V) * ce_ldp(V) + gemm_wide_part_floats(200, true) + 16;
 }
 
 // dX [N,E] overwritten; dW [V,E], db [V] overwritten.
@@ -618,17 +433,19 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
                             float* dX, float* dW, float* db, float* ws, hipStream_t s) {
   CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && R > 0 && TR % R == 0 && N % TR == 0 && N < (1L << 31),
                "ce_backward: bad shape");
-  CVAE_TRY(check_hip(hipMemsetAsync(dW, 0, (size_t)V * E * sizeof(float), s), "dW memset"));
-  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)V * sizeof(float), s), "db memset"));
+  CVAE_TRY(launch_zero(dW, (long)V * E, s));
+  CVAE_TRY(launch_zero(db, V, s));
   if (N == 0) return 0;
   CVAE_REQUIRE(X && W && bias && tgt && lse && gsent && dX && dW && db && ws, "ce_backward: null operand");
-  CVAE_TRY(check_hip(hipMemsetAsync(dX, 0, (size_t)N * E * sizeof(float), s), "dX memset"));
+  CVAE_TRY(launch_zero(dX, N * E, s));
   int* rows = reinterpret_cast<int*>(ws);
   int* counts = rows + N;
   int* nlive = counts + ce_counts_slots(N) - 4;
   float* P = ws + N + ce_counts_slots(N) + 16;
   P = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(P) + 15) & ~(uintptr_t)15);
   const long ldp = ce_ldp(V), CH = ce_chunk_rows(N, V);
+  float* part = P + CH * ldp;
+  part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(part) + 15) & ~(uintptr_t)15);
   CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, nullptr, nullptr, nullptr, s));
   CeArgs a = {};
   a.X = X; a.W = W; a.bias = bias; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
@@ -644,13 +461,13 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
     }
     G224Args gx = {};      // dX[rows[r0+m], :] += P[m, :] . W
     gx.A = P; gx.lda = ldp; gx.B = W; gx.ldb = E; gx.C = dX; gx.ldc = E;
-    gx.M = rc; gx.N = E; gx.K = V; gx.nlive = nlive; gx.r0 = (int)r0; gx.dev_bound = 1; gx.rows = rows;
-    CVAE_TRY(launch_gemm224(true, gx, s));
+    gx.M = rc; gx.N = E; gx.K = V; gx.nlive = nlive; gx.r0 = (int)r0; gx.dev_bound = 1; gx.rows = rows; gx.part = part;
+    CVAE_TRY(launch_gemm_wide(true, gx, s));
     G224Args gw = {};      // [dW | db] += P^T . [X[rows[r0+k], :] | 1]
     gw.A = P; gw.lda = ldp; gw.B = X; gw.ldb = E; gw.C = dW; gw.ldc = E;
     gw.M = V; gw.N = E; gw.K = rc; gw.nlive = nlive; gw.r0 = (int)r0; gw.dev_bound = 2; gw.rows = rows;
-    gw.extra = db;
-    CVAE_TRY(launch_gemm224(false, gw, s));
+    gw.extra = db; gw.beta = 1; gw.part = part;
+    CVAE_TRY(launch_gemm_wide(false, gw, s));
   }
   return 0;
 }

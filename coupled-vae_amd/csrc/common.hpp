@@ -89,6 +89,26 @@ struct GemmDesc {
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 
+// Long-K split-K product with a few hundred output columns (gemm_wide.hip): C += A . B, B = [k][n].
+struct G224Args {
+  const float* A; long lda;
+  const float* B; long ldb;
+  float* C; long ldc;
+  int M, N, K;
+  const int* nlive; int r0;   // optional device-side bound: lim = max(0, *nlive - r0)
+  int dev_bound;              // 0: none; 1: M <= lim, C row = rows[r0 + m]; 2: K <= lim, B row = rows[r0 + k]
+  const int* rows;
+  float* extra;               // optional [M]: extra[m] (+)= sum_k A[m,k] (a ones column appended to B; N <= 220)
+  int beta;                   // 0: C (and extra) overwritten, 1: accumulated into
+  float* part;                // partial-sum slabs (gemm_wide_part_floats); null -> library scratch
+  int ntiles, tile_w, part_ld;   // filled by the launcher
+  int vecA, vecB, vecC;
+};
+long gemm_wide_part_floats(int N, bool extra);
+int launch_gemm_wide(bool a_k_contiguous, G224Args a, hipStream_t s);
+int persistent_grid_blocks();
+int launch_zero(float* p, long n, hipStream_t s);
+
 // Few-row product with the K dimension split over the waves of a block (skinny.hip).
 enum SkinnyEpi { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2, EPI_GRU_BWD = 3, EPI_LSTM_BWD = 4 };
 struct SkinnyArgs {

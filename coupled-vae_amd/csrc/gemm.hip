@@ -171,6 +171,14 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     a.C = d.C; a.ldc = d.ldc; a.bias = d.bias; a.act = d.act; a.beta = d.beta;
     return launch_skinny(a, EPI_LINEAR, s);
   }
+  // Long-K products with a k-major B and at most a few hundred columns (weight gradients over
+  // T*B rows, input gradients): persistent split-K kernel of gemm_wide.hip.
+  if (!d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= 448 && d.M >= 64) {
+    G224Args w = {};
+    w.A = d.A; w.lda = d.lda; w.B = d.B; w.ldb = d.ldb; w.C = d.C; w.ldc = d.ldc;
+    w.M = d.M; w.N = d.N; w.K = d.K; w.beta = d.beta;
+    return launch_gemm_wide(!d.transA, w, s);
+  }
   const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
   if (tiles128 >= 192) return launch_tiled<128, 128>(d, s);
   return launch_tiled<64, 64>(d, s);

@@ -1,0 +1,335 @@
+// Split-K GEMM for "few hundred columns" outputs:  C[M,N] += A[M,K] . B[K,N],  B stored [k][n].
+// These are the long-K contractions of the training step: the two products that consume the
+// softmax gradient (dX = P W, [dW | db] += P^T [X | 1]) and the weight gradients of the
+// recurrent layers (dW = dG^T X over T*B rows).
+//
+//  * persistent grid (2 blocks / CU); the (m-tile, n-tile, k-range) work items are laid out on
+//    the DEVICE, because for the CE products the live-row count that bounds M or K only exists
+//    in device memory (ce_fast.hip);
+//  * block tile 128 x (NF*32) columns, 4 waves x 32 rows, v_mfma_f32_32x32x2_f32; BK = 16,
+//    double-buffered LDS, one barrier per chunk, fragments for MFMA step s+1 are read while
+//    step s issues;
+//  * A is read k-contiguous ([m][k], float4 per lane = 4 MFMA steps) or k-major ([k][m]);
+//    B fragments are read with one b128 (+ one b64 + one b32 when NF = 7) per step: the column
+//    permutation this implies is undone in the epilogue;
+//  * no atomics (13M float atomics cost ~180 us on MI355X, more than the product itself): with
+//    one k-range per tile the block stores C directly, otherwise every item stores its partial
+//    tile to a slab and gemm_wide_reduce_kernel adds the slabs in a fixed order (deterministic).
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace cvae {
+
+constexpr int G2_BM = 128, G2_BK = 16, G2_LDA = 20;
+
+int persistent_grid_blocks() {
+  static int nblk = 0;
+  if (!nblk) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    nblk = 2 * cus;
+  }
+  return nblk;
+}
+
+__device__ __forceinline__ float4 ld4g(const float* __restrict__ src, int k, int K, int vec) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && k + 3 < K) {
+    r = *reinterpret_cast<const float4*>(src);
+  } else {
+    if (k + 0 < K) r.x = src[0];
+    if (k + 1 < K) r.y = src[1];
+    if (k + 2 < K) r.z = src[2];
+    if (k + 3 < K) r.w = src[3];
+  }
+  return r;
+}
+
+// Work layout, computed identically by the GEMM blocks and by the reduction kernel.
+struct WideLayout { int Mlim, Klim, mt, ks, kchunk; };
+__device__ __forceinline__ WideLayout wide_layout(const G224Args& p, int nblk) {
+  WideLayout w;
+  w.Mlim = p.M; w.Klim = p.K;
+  if (p.dev_bound) {
+    int lim = *p.nlive - p.r0;
+    if (lim < 0) lim = 0;
+    if (p.dev_bound == 1) w.Mlim = min(w.Mlim, lim); else w.Klim = min(w.Klim, lim);
+  }
+  w.mt = (w.Mlim + G2_BM - 1) / G2_BM;
+  const int kunits = (w.Klim + G2_BK - 1) / G2_BK;
+  int ks = (w.mt > 0) ? nblk / (w.mt * p.ntiles) : 1;
+  if (ks > kunits / 4) ks = kunits / 4;      // at least 4 chunks per item
+  if (ks < 1) ks = 1;
+  w.kchunk = ((kunits + ks - 1) / ks) * G2_BK;
+  w.ks = (w.kchunk > 0) ? (w.Klim + w.kchunk - 1) / w.kchunk : 1;
+  return w;
+}
+
+// NF = 4: 128-column tiles; NF = 7: 224-column tiles (fragments 4,5 from a b64, 6 from a b32)
+template <bool AKC, int NF>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
+  constexpr int BN = NF * 32;
+  __shared__ __attribute__((aligned(16))) float As[2][AKC ? G2_BM * G2_LDA : G2_BK * G2_BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][G2_BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const WideLayout L = wide_layout(p, gridDim.x);
+  const int Mlim = L.Mlim, Klim = L.Klim;
+  if (Mlim <= 0 || Klim <= 0) return;
+  const int mt = L.mt, nt = p.ntiles, ks = L.ks, kchunk = L.kchunk;
+  const int items = mt * nt * ks;
+
+  const int tw = p.tile_w;                    // columns per n-tile (multiple of 4, <= BN - 4 when extra)
+  const int nf4 = tw >> 2;                    // float4 per staged B row
+  const int ones_col = p.extra ? tw : -1;
+
+  // columns of the LDS image that staging never writes: zero, except the ones column
+  for (int i = tid; i < 2 * G2_BK * BN; i += 256) {
+    const int c = i % BN;
+    if (c >= tw) (&Bs[0][0])[i] = (c == ones_col) ? 1.f : 0.f;
+  }
+  int bkr[4], bc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    bkr[i] = (idx < G2_BK * nf4) ? idx / nf4 : -1;
+    bc[i] = 4 * (idx % nf4);
+  }
+  __syncthreads();
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int ntile = item % nt, mtile = (item / nt) % mt, ksp = item / (nt * mt);
+    const int m0 = mtile * G2_BM, n0 = ntile * tw;
+    const int ncols = min(tw, p.N - n0);
+    const int kbeg = ksp * kchunk, kend = min(Klim, kbeg + kchunk);
+
+    float4 sa[2], sb[4];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AKC) {
+          const int row = m0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+          if (row < Mlim && k < kend) v = ld4g(p.A + (long)row * p.lda + k, k, kend, p.vecA);
+        } else {
+          const int k = k0 + (idx >> 5), m = m0 + 4 * (idx & 31);
+          if (k < kend && m < Mlim) v = ld4g(p.A + (long)k * p.lda + m, m, Mlim, p.vecA);
+        }
+        sa[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = k0 + bkr[i];
+        if (bkr[i] >= 0 && k < kend && bc[i] < ncols) {
+          const long brow = (p.dev_bound == 2) ? (long)p.rows[p.r0 + k] : (long)k;
+          v = ld4g(p.B + brow * p.ldb + n0 + bc[i], bc[i], ncols, p.vecB);
+        }
+        sb[i] = v;
+      }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        if (AKC) *reinterpret_cast<float4*>(&As[buf][(idx >> 2) * G2_LDA + 4 * (idx & 3)]) = sa[i];
+        else *reinterpret_cast<float4*>(&As[buf][(idx >> 5) * G2_BM + 4 * (idx & 31)]) = sa[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (bkr[i] >= 0) *reinterpret_cast<float4*>(&Bs[buf][bkr[i] * BN + bc[i]]) = sb[i];
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    stage_load(kbeg);
+    stage_store(0);
+    __syncthreads();
+    const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) stage_load(kbeg + (kt + 1) * G2_BK);
+      // the chunk's 8 MFMA steps: (q, s) uses k = 8q + 4*lhi + s
+      float a[8];
+      if (AKC) {
+        const float* ar = &As[buf][(wave * 32 + l31) * G2_LDA + 4 * lhi];
+        const float4 a0 = *reinterpret_cast<const float4*>(ar);
+        const float4 a1 = *reinterpret_cast<const float4*>(ar + 8);
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+        a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+      } else {
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+          a[st] = As[buf][(8 * (st >> 2) + 4 * lhi + (st & 3)) * G2_BM + wave * 32 + l31];
+      }
+      const float* bbase = &Bs[buf][(4 * lhi) * BN];
+      float4 b0[2];
+      float2 b1[2];
+      float b2[2];
+      auto bread = [&](int st, int slot) {
+        const float* br = bbase + (8 * (st >> 2) + (st & 3)) * BN;
+        b0[slot] = *reinterpret_cast<const float4*>(br + 4 * l31);
+        if (NF == 7) {
+          b1[slot] = *reinterpret_cast<const float2*>(br + 128 + 2 * l31);
+          b2[slot] = br[192 + l31];
+        }
+      };
+      bread(0, 0);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < 8) bread(st + 1, cur ^ 1);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b0[cur].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b0[cur].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b0[cur].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b0[cur].w, acc[3], 0, 0, 0);
+        if (NF == 7) {
+          acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b1[cur].x, acc[4], 0, 0, 0);
+          acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b1[cur].y, acc[5], 0, 0, 0);
+          acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b2[cur], acc[6], 0, 0, 0);
+        }
+      }
+      if (kt + 1 < nk) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+
+    // epilogue: acc[j][r] -> row m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lhi ; column by fragment.
+    // ks == 1: final values go straight to C (plain stores, or += when accumulating);
+    // ks  > 1: this item's partial sums go to its slab part[ksp][row][col] (plain stores) and
+    //          gemm_wide_reduce_kernel adds the slabs in a fixed order.
+    const bool direct = (ks == 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row >= Mlim) continue;
+      float* c;
+      if (direct) {
+        const long crow = (p.dev_bound == 1) ? (long)p.rows[p.r0 + row] : (long)row;
+        c = p.C + crow * p.ldc + n0;
+      } else {
+        c = p.part + ((long)(ksp * mt + mtile) * G2_BM + (row - m0)) * p.part_ld + n0;
+      }
+      const bool acc_c = direct && p.beta;
+      auto put = [&](int cj, float v) {            // one element: a real column, the ones column, or nothing
+        if (cj < ncols) c[cj] = v + (acc_c ? c[cj] : 0.f);
+        else if (cj == ones_col) {
+          if (direct) p.extra[row] = v + (p.beta ? p.extra[row] : 0.f);
+          else c[p.N] = v;                         // slab column N (one n-tile when extra: n0 == 0)
+        }
+      };
+      // fragments 0-3: four consecutive columns per lane
+      const int c0 = 4 * l31;
+      if (c0 + 3 < ncols && (direct ? p.vecC : 1)) {
+        float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        float4* d = reinterpret_cast<float4*>(c + c0);
+        if (acc_c) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *d = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(c0 + j, acc[j][r]);
+      }
+      if (NF == 7) {
+        put(128 + 2 * l31, acc[4][r]);
+        put(128 + 2 * l31 + 1, acc[5][r]);
+        put(192 + l31, acc[6][r]);
+      }
+    }
+  }
+}
+
+// C (+)= sum over the ks slabs, in slab order (deterministic).  One thread per (row, 4 columns).
+__global__ __launch_bounds__(256) void gemm_wide_reduce_kernel(G224Args p, int nblk) {
+  const WideLayout L = wide_layout(p, nblk);
+  if (L.ks <= 1 || L.Mlim <= 0 || L.Klim <= 0) return;
+  const int ncol = p.N + (p.extra ? 1 : 0);
+  const int nc4 = (ncol + 3) >> 2;
+  const long total = (long)L.Mlim * nc4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / nc4), c0 = 4 * (int)(i % nc4);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < L.ks; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(
+          p.part + ((long)(k * L.mt + row / G2_BM) * G2_BM + row % G2_BM) * p.part_ld + c0);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const long crow = (p.dev_bound == 1) ? (long)p.rows[p.r0 + row] : (long)row;
+    float* c = p.C + crow * p.ldc;
+    const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c0 + j;
+      if (col < p.N) c[col] = sv[j] + (p.beta ? c[col] : 0.f);
+      else if (p.extra && col == p.N) p.extra[row] = sv[j] + (p.beta ? p.extra[row] : 0.f);
+    }
+  }
+}
+
+// Partial-sum slabs: at most persistent_grid_blocks() tiles of 128 rows are in flight per launch.
+long gemm_wide_part_floats(int N, bool extra) {
+  const long ld = (N + (extra ? 1 : 0) + 3) / 4 * 4;
+  return (long)persistent_grid_blocks() * G2_BM * ld;
+}
+
+// Library-owned scratch for callers that bring none (one buffer per process, grown on demand;
+// launches that share it must be on one stream).
+static float* g_part = nullptr;
+static long g_part_floats = 0;
+static int lib_part(long floats, float** out) {
+  if (floats > g_part_floats) {
+    if (g_part) CVAE_TRY(check_hip(hipFree(g_part), "gemm_wide scratch free"));   // implicit device sync
+    g_part = nullptr; g_part_floats = 0;
+    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_part), (size_t)floats * sizeof(float)), "gemm_wide scratch"));
+    g_part_floats = floats;
+  }
+  *out = g_part;
+  return 0;
+}
+
+int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
+  CVAE_REQUIRE(a.N > 0, "gemm_wide: N=%d", a.N);
+  CVAE_REQUIRE(a.extra == nullptr || a.N <= 220, "gemm_wide: the ones column needs N <= 220 (N=%d)", a.N);
+  if (a.M <= 0 || a.K <= 0) return 0;
+  // balanced n-tiles: 224-wide fragments when that saves MFMA columns, else 128-wide
+  const int n_eff = a.N + (a.extra ? 1 : 0);
+  const int nt7 = cdiv(n_eff, 224), nt4 = cdiv(n_eff, 128);
+  const bool wide = (7 * nt7 < 4 * nt4) || a.extra;
+  a.ntiles = wide ? nt7 : nt4;
+  a.tile_w = cdiv(cdiv(a.N, a.ntiles), 4) * 4;
+  a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
+  a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
+  a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
+  a.part_ld = (n_eff + 3) / 4 * 4;
+  if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part));
+  const int nblk = persistent_grid_blocks();
+  const dim3 grid(nblk), block(256);
+  {
+    ProfScope prof(PK_GEMM_TILED, s, 2.0 * a.M * a.N * a.K);
+    if (akc) {
+      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<true, 7>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, block, 0, s, a);
+    } else {
+      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<false, 7>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_wide_kernel<false, 4>), grid, block, 0, s, a);
+    }
+  }
+  CVAE_LAUNCH_CHECK("gemm_wide_kernel");
+  // the reduction is a no-op (early exit) when the device picked one k-range per tile
+  if ((long)cdiv(a.M, G2_BM) * a.ntiles * 2 <= nblk || a.dev_bound) {
+    const long total = (long)a.M * (a.part_ld / 4);
+    int rb = (int)((total + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(gemm_wide_reduce_kernel, dim3(rb), dim3(256), 0, s, a, nblk);
+    CVAE_LAUNCH_CHECK("gemm_wide_reduce_kernel");
+  }
+  return 0;
+}
+
+}  // namespace cvae

@@ -45,6 +45,12 @@ GEMM_CASES = [
     (100, 64, 5000, 0, 0, 0, 0, 1),        # split-K accumulate
     (130, 70, 33, 1, 1, 1, 3, 0),          # both transposed, exp
     (1, 1, 1, 0, 1, 0, 0, 0),
+    # long-K, few-hundred-column products -> persistent split-K kernel (gemm_wide.hip)
+    (1024, 256, 3001, 1, 0, 0, 0, 0),      # dW_hh: two 128-column tiles, ragged K
+    (1024, 200, 6432, 1, 0, 0, 0, 1),      # dW_ih accumulate: one 224-wide tile
+    (333, 131, 517, 0, 0, 0, 0, 0),        # ragged M/N/K, 224-wide tile with 131 live columns
+    (70, 447, 600, 1, 0, 0, 0, 0),         # two 224-wide tiles, unaligned N
+    (6432, 200, 1024, 0, 0, 0, 0, 0),      # dX = dG W_ih
 ]
 
 
