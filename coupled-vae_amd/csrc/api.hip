@@ -88,7 +88,7 @@ static int grad_input(const float* dy, long lddy, const float* W, long ldw, int 
 }
 
 static int grad_bias(const float* dy, int M, int N, long ld, float* db, hipStream_t s) {
-  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s), "bias grad memset"));
+  CVAE_TRY(launch_zero(db, (long)N, s));
   return launch_colsum_acc(dy, M, N, ld, db, s);
 }
 
@@ -389,7 +389,7 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
     CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre, s));
     CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, q.dw[4], 0, s));
     CVAE_TRY(grad_bias(dpre, T * B, E, E, q.dw[5], s));
-    CVAE_TRY(check_hip(hipMemsetAsync(dhs, 0, (size_t)BH * sizeof(float), s), "dhs[0] memset"));
+    CVAE_TRY(launch_zero(dhs, (long)BH, s));
     CVAE_TRY(grad_input(dpre, E, q.w[4], Hd, T * B, E, Hd, dhs + BH, Hd, 0, s));
     if (q.mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, q.mask_out, dhs + BH, s));
     r[d].cell = cell; r[d].T = T1; r[d].R = B; r[d].H = Hd; r[d].reverse = 0;
@@ -484,8 +484,8 @@ int cvae_projce_backward(const float* final, const float* W, const float* b, con
   const long TR = (long)T * R, N = TR * nseg;
   if (ce_fast_supported(E))
     return launch_ce_fast_backward(final, W, b, tgt, pad, lse, gsent, N, TR, R, E, (int)V, dfinal, dW, db, ws, s);
-  CVAE_TRY(check_hip(hipMemsetAsync(dW, 0, (size_t)V * E * sizeof(float), s), "dW memset"));
-  CVAE_TRY(check_hip(hipMemsetAsync(db, 0, (size_t)V * sizeof(float), s), "db memset"));
+  CVAE_TRY(launch_zero(dW, (long)V * E, s));
+  CVAE_TRY(launch_zero(db, (long)V, s));
   for (int g = 0; g < nseg; ++g) {
     float* grow = ws;
     CVAE_TRY(launch_bcast_time(gsent + (long)g * R, T, R, grow, s));

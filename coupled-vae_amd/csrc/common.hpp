@@ -108,6 +108,7 @@ long gemm_wide_part_floats(int N, bool extra);
 int launch_gemm_wide(bool a_k_contiguous, G224Args a, hipStream_t s);
 int persistent_grid_blocks();
 int launch_zero(float* p, long n, hipStream_t s);
+int launch_copy(float* dst, const float* src, long n, hipStream_t s);
 
 // Few-row product with the K dimension split over the waves of a block (skinny.hip).
 enum SkinnyEpi { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2, EPI_GRU_BWD = 3, EPI_LSTM_BWD = 4 };

@@ -135,7 +135,7 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 1 && !d.beta) {
     if (d.ldc == d.N) {
-      CVAE_TRY(check_hip(hipMemsetAsync(d.C, 0, (size_t)d.M * d.N * sizeof(float), s), "gemm split-K memset"));
+      CVAE_TRY(launch_zero(d.C, (long)d.M * d.N, s));
     } else {
       CVAE_TRY(check_hip(hipMemset2DAsync(d.C, d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), d.M, s),
                          "gemm split-K memset2D"));

@@ -117,7 +117,7 @@ __global__ void embed_scatter_kernel(int T, int B, int E, int W, int slot0, cons
     const long mr = mask_rows ? mask_rows[b] : b;
     v *= mask[((long)t * B + mr) * W + e];
   }
-  atomicAdd(demb + ids[(long)b * T + t] * E + e, v);
+  if (v != 0.f) atomicAdd(demb + ids[(long)b * T + t] * E + e, v);   // padded steps / dropped elements: exact zeros
 }
 
 int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* ids, const float* dX,
@@ -130,22 +130,33 @@ int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* i
 }
 
 // dinit[b,e] = dX[0,b,e] + dX[0,b,E+e] + sum_t dX[1+t,b,E+e] * mask[t,b,E+e]
-__global__ void dec_dinit_kernel(int T, int B, int E, const float* __restrict__ dX, const float* __restrict__ mask,
-                                 float* __restrict__ dinit) {
-  IDX1D((long)B * E);
-  const int e = (int)(idx % E), b = (int)(idx / E);
+__global__ __launch_bounds__(1024) void dec_dinit_kernel(int T, int B, int E, const float* __restrict__ dX,
+                                                         const float* __restrict__ mask, float* __restrict__ dinit) {
+  // block = (b, 64 columns); its 16 waves take the time steps round-robin, fixed summation order
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, e = blockIdx.x * 64 + lane;
   const long W = 2L * E;
-  float acc = dX[(long)b * W + e] + dX[(long)b * W + E + e];
-  for (int t = 0; t < T; ++t) {
-    float v = dX[((long)(t + 1) * B + b) * W + E + e];
-    if (mask) v *= mask[((long)t * B + b) * W + E + e];
-    acc += v;
+  float acc = 0.f;
+  if (e < E)
+    for (int t = wave; t < T; t += 16) {
+      float v = dX[((long)(t + 1) * B + b) * W + E + e];
+      if (mask) v *= mask[((long)t * B + b) * W + E + e];
+      acc += v;
+    }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && e < E) {
+    float tot = dX[(long)b * W + e] + dX[(long)b * W + E + e];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += part[w][lane];
+    dinit[(long)b * E + e] = tot;
   }
-  dinit[idx] = acc;
 }
 
 int launch_dec_dinit(int T, int B, int E, const float* dX, const float* mask, float* dinit, hipStream_t s) {
-  hipLaunchKernelGGL(dec_dinit_kernel, GRID1D((long)B * E), 0, s, T, B, E, dX, mask, dinit);
+  if ((long)B * E == 0) return 0;
+  hipLaunchKernelGGL(dec_dinit_kernel, dim3(cdiv(E, 64), B), dim3(1024), 0, s, T, B, E, dX, mask, dinit);
   CVAE_LAUNCH_CHECK("dec_dinit_kernel");
   return 0;
 }
@@ -207,6 +218,20 @@ int launch_zero(float* p, long n, hipStream_t s) {
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n4, n, p);
   CVAE_LAUNCH_CHECK("zero_kernel");
+  return 0;
+}
+
+// dst[0..n) = src[0..n)  (same host-cost argument as launch_zero vs hipMemcpyAsync)
+__global__ __launch_bounds__(256) void copy_kernel(long n, const float* __restrict__ src, float* __restrict__ dst) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = src[k];
+}
+int launch_copy(float* dst, const float* src, long n, hipStream_t s) {
+  if (n <= 0) return 0;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n, src, dst);
+  CVAE_LAUNCH_CHECK("copy_kernel");
   return 0;
 }
 
@@ -567,8 +592,9 @@ int launch_mi(const float* z, const float* mu, const float* sigma, int K, int B,
 
 // ------------------------------------------------------------------ clip + Adam (a12)
 // sumsq[0] = sum over all grads^2, sumsq[1] = sum over the alias segment
-__global__ __launch_bounds__(256) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
-                                                    float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
+                                                     float* __restrict__ out) {
+  __shared__ float red[2][16];
   float all = 0.f, al = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = g[i];
@@ -576,9 +602,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, long a0, long a1, co
     if (i >= a0 && i < a1) al += v * v;
   }
   all = wave_sum(all); al = wave_sum(al);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(out, all);
-    if (al != 0.f) atomicAdd(out + 1, al);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = all; red[1][wave] = al; }
+  __syncthreads();
+  if (threadIdx.x == 0) {           // same-address float atomics cost ~12 ns each: one pair per block
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
+    atomicAdd(out, s0);
+    if (s1 != 0.f) atomicAdd(out + 1, s1);
   }
 }
 
@@ -621,11 +653,14 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
                "clip_adam: bad segment (alias_mult must be 1..8)");
   if (n == 0) return 0;
   CVAE_REQUIRE(p && g && m && v && sumsq, "clip_adam: null operand");
-  CVAE_TRY(check_hip(hipMemsetAsync(sumsq, 0, 2 * sizeof(float), s), "clip_adam memset"));
+  CVAE_TRY(launch_zero(sumsq, 2, s));
   int grid = cdiv(n, 256 * 8);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, g, sumsq);
+  int sgrid = cdiv(n, 1024 * 8);
+  if (sgrid > 256) sgrid = 256;
+  if (sgrid < 1) sgrid = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, sumsq);
   CVAE_LAUNCH_CHECK("sumsq_kernel");
   AdamSteps so = {}, sa = {};
   so.step_size[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_other + 1))));

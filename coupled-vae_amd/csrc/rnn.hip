@@ -77,11 +77,11 @@ static int rnn_forward_init(const RnnFwd& a, hipStream_t s) {
   const long RH = (long)a.R * a.H;
   const int init_slot = a.reverse ? a.T : 0;
   if (a.init_in_place) return 0;
-  if (a.h0) CVAE_TRY(check_hip(hipMemcpyAsync(a.hs + init_slot * RH, a.h0, RH * 4, hipMemcpyDeviceToDevice, s), "h0 copy"));
-  else CVAE_TRY(check_hip(hipMemsetAsync(a.hs + init_slot * RH, 0, RH * 4, s), "h0 memset"));
+  if (a.h0) CVAE_TRY(launch_copy(a.hs + init_slot * RH, a.h0, RH, s));
+  else CVAE_TRY(launch_zero(a.hs + init_slot * RH, RH, s));
   if (a.cell == CELL_LSTM) {
-    if (a.c0) CVAE_TRY(check_hip(hipMemcpyAsync(a.cs + init_slot * RH, a.c0, RH * 4, hipMemcpyDeviceToDevice, s), "c0 copy"));
-    else CVAE_TRY(check_hip(hipMemsetAsync(a.cs + init_slot * RH, 0, RH * 4, s), "c0 memset"));
+    if (a.c0) CVAE_TRY(launch_copy(a.cs + init_slot * RH, a.c0, RH, s));
+    else CVAE_TRY(launch_zero(a.cs + init_slot * RH, RH, s));
   }
   return 0;
 }
@@ -237,11 +237,11 @@ int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
   for (int q = 0; q < ns; ++q) {
     const RnnBwd& a = arr[q];
     CVAE_REQUIRE(a.whhT, "rnn_backward: whhT scratch required for R <= %d", SKINNY_MAX_ROWS);
-    if (a.dh_last) CVAE_TRY(check_hip(hipMemcpyAsync(a.dh0, a.dh_last, RH * 4, hipMemcpyDeviceToDevice, s), "dh_last copy"));
-    else CVAE_TRY(check_hip(hipMemsetAsync(a.dh0, 0, RH * 4, s), "dh memset"));
+    if (a.dh_last) CVAE_TRY(launch_copy(a.dh0, a.dh_last, RH, s));
+    else CVAE_TRY(launch_zero(a.dh0, RH, s));
     if (a.cell == CELL_LSTM) {
-      if (a.dc_last) CVAE_TRY(check_hip(hipMemcpyAsync(a.dc0, a.dc_last, RH * 4, hipMemcpyDeviceToDevice, s), "dc_last copy"));
-      else CVAE_TRY(check_hip(hipMemsetAsync(a.dc0, 0, RH * 4, s), "dc memset"));
+      if (a.dc_last) CVAE_TRY(launch_copy(a.dc0, a.dc_last, RH, s));
+      else CVAE_TRY(launch_zero(a.dc0, RH, s));
     }
     if (T == 0) continue;
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(G * H, 32)), dim3(256), 0, s, G * H, H, a.W_hh, a.whhT);
@@ -290,11 +290,11 @@ static int rnn_backward_large(const RnnBwd& a, hipStream_t s) {
   float* dhb[2] = {a.dh0, a.dh_tmp};
   float* dcb[2] = {a.dc0, a.dc_tmp};
   int cur = a.T & 1;
-  if (a.dh_last) CVAE_TRY(check_hip(hipMemcpyAsync(dhb[cur], a.dh_last, RH * 4, hipMemcpyDeviceToDevice, s), "dh_last copy"));
-  else CVAE_TRY(check_hip(hipMemsetAsync(dhb[cur], 0, RH * 4, s), "dh memset"));
+  if (a.dh_last) CVAE_TRY(launch_copy(dhb[cur], a.dh_last, RH, s));
+  else CVAE_TRY(launch_zero(dhb[cur], RH, s));
   if (a.cell == CELL_LSTM) {
-    if (a.dc_last) CVAE_TRY(check_hip(hipMemcpyAsync(dcb[cur], a.dc_last, RH * 4, hipMemcpyDeviceToDevice, s), "dc_last copy"));
-    else CVAE_TRY(check_hip(hipMemsetAsync(dcb[cur], 0, RH * 4, s), "dc memset"));
+    if (a.dc_last) CVAE_TRY(launch_copy(dcb[cur], a.dc_last, RH, s));
+    else CVAE_TRY(launch_zero(dcb[cur], RH, s));
   }
   for (int i = a.T - 1; i >= 0; --i) {      // undo the forward order
     const int t = a.reverse ? a.T - 1 - i : i;
