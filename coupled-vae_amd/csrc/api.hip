@@ -557,6 +557,8 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
   return launch_clip_adam(params, grads, m, v, n, alias_off, alias_n, alias_mult, max_norm, lr, beta1, beta2, eps,
                           step_other, step_alias, sumsq, norm_out, S(stream));
 }
+int cvae_persist_status(void) { return persist_status_and_clear(); }
+
 int cvae_sum_time(const float* x, int T, int R, float* out, void* stream) {
   return launch_sum_time(x, T, R, out, S(stream));
 }

@@ -180,5 +180,11 @@ struct RnnBwd {
 };
 int launch_rnn_backward(const RnnBwd& a, hipStream_t s);
 int launch_rnn_backward_multi(const RnnBwd* a, int ns, hipStream_t s);
+// rnn_persist.hip: all T steps of up to four lock-stepped sequences in one launch (R <= 32)
+bool rnn_persist_supported(int cell, int T, int R, int H, int ns);
+bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns);
+int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s);    // initial slots already set
+int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s);
+int persist_status_and_clear();
 
 }  // namespace cvae

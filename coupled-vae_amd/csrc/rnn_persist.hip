@@ -1,0 +1,566 @@
+// Whole-sequence GRU / LSTM kernels for training batch sizes (R <= 32 rows per sequence):
+// ONE launch runs all T steps of up to four lock-stepped recurrences (the two encoder directions,
+// the decoder and its coupled twin), instead of one launch per step.
+// Reference semantics: nn.GRU / nn.LSTM as used by CV/Modules/encoder.py:27-39 and
+// CV/Modules/vae_couple.py:58-70 (same cell equations as cell_fwd_kernel / cell_bwd_point).
+//
+// Why: at B = 32 a step is 67 MFLOP; the per-step kernels of rnn.hip / skinny.hip spend ~7.5 us in
+// launch, operand fetch (W_hh is re-read from L2 every step) and drain, plus ~1.5 us of kernel
+// boundary.  Here every block keeps ITS slice of W_hh resident for the whole sequence and the steps
+// are separated by an in-kernel all-gather of the 32 x H state:
+//   * grid = (H / 4) blocks per sequence, one block per CU (<= 256 blocks in all): block b owns
+//     hidden units 4b .. 4b+3, i.e. 4*G gate columns (forward) or 4 columns of dh (backward);
+//   * forward step:  gates[32 x 4G] = h_{t-1}[32 x H] . W_hh[4G rows]^T with v_mfma_f32_16x16x4_f32,
+//     K split over the block's waves (W fragments live in registers), partial tiles summed through
+//     LDS, then 128 threads run the cell for their (row, unit) and publish h_t;
+//   * backward step: dh_{t-1}[32 x 4] = dG_t[32 x G*H] . W_hh[:, 4 units] with
+//     v_mfma_f32_4x4x1_16b_f32 (16 blocks = 8 row groups x 2 K halves: no padding of the 4-column
+//     tile), W slice in LDS, then the cell backward of step t-1 for the block's units, which
+//     publishes dG_{t-1};
+//   * hand-off between blocks (MI355X_MICROARCH.md, inter-workgroup visibility, first table row):
+//     payload stored write-through (`sc1` buffer stores), every storing wave drains (vmcnt(0)),
+//     workgroup barrier, ONE lane adds to the sequence's agent-scope counter; consumers poll that
+//     counter with `sc1` loads (one lane, bounded), barrier, then read the payload with `sc1`
+//     buffer loads.  Every spin is bounded: on a timeout the block raises the status word and the
+//     whole grid drains (cvae_persist_status reports it).
+#include "common.hpp"
+#include "cell_math.hpp"
+
+namespace cvae {
+
+constexpr int P_HU = 4;              // hidden units per block
+constexpr int P_THREADS = 1024;      // 16 waves
+constexpr unsigned P_SPIN_LIMIT = 1u << 19;
+constexpr int P_MAXB = 128;          // blocks per sequence (H <= 512)
+constexpr int P_AUX_SC1 = 16;        // buffer load/store aux bit: sc1 (write-through / L1 bypass)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+struct PSeqF {
+  const float* xproj; const float* xadd; const float* W_hh; const float* b_hh; const int64_t* lengths;
+  float* hs; float* cs; float* gates;
+  int xmod, reverse;
+};
+struct PFwdArgs {
+  PSeqF q[SKINNY_MAX_BATCH];
+  int T, R, H, nw;                   // nw: waves that take part in the K split (H / nw multiple of 16)
+  unsigned* flags;                   // [ns][P_MAXB] epoch flags, zero at launch
+  int* status;
+  unsigned long long* stamps;
+};
+
+struct PSeqB {
+  const float* dhs; const float* dh_last; const float* dc_last;
+  const float* hs; const float* cs; const float* gates; const float* W_hh; const int64_t* lengths;
+  float* dgx; float* dgh;            // dgh == dgx for LSTM
+  float* dh0; float* dc0;
+  int reverse;
+};
+struct PBwdArgs {
+  PSeqB q[SKINNY_MAX_BATCH];
+  int T, R, H;
+  unsigned* flags;
+  int* status;
+  unsigned long long* stamps;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4v ld16_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
+  const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, P_AUX_SC1);
+  return __builtin_bit_cast(f32x4v, v);
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, long float_off, f32x4v v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, (int)(float_off * 4), 0, P_AUX_SC1);
+}
+
+// Per-block epoch flags (no atomics: 128 arrivals on one counter serialise at ~12 ns each).
+// All threads call; wave 0 polls the sequence's nb flags (one sc1 load per lane per 64 blocks).
+// Returns false (uniformly) on timeout.
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int nb, unsigned epoch, int* status, int* s_abort) {
+  if (threadIdx.x < 64) {
+    unsigned spins = 0;
+    int bad = 0;
+    for (;;) {
+      int ok = 1;
+      for (int k = threadIdx.x; k < nb; k += 64)
+        ok &= (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) ? 1 : 0;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > P_SPIN_LIMIT) { bad = 1; break; }
+    }
+    if (threadIdx.x == 0) {
+      if (bad) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_abort = bad;
+    }
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+// Every storing wave has drained; one lane raises this block's flag (sc1 store).
+__device__ __forceinline__ void publish(unsigned* flags, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// optional phase stamps (diagnostics, CVAE_PERSIST_STAMPS=1): block (0,0) thread 0 accumulates cycles
+#define P_STAMP(k)                                                                 \
+  do {                                                                             \
+    if (stamp_on) {                                                                \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+      sacc_[k] += now_ - tprev_;                                                   \
+      tprev_ = now_;                                                               \
+    }                                                                              \
+  } while (0)
+
+// --------------------------------------------------------------------------------------- forward
+template <int CELL>
+__global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  constexpr int NC = P_HU * G;                       // live gate columns of this block (12 / 16)
+  __shared__ float red[16][32][16];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const PSeqF& q = p.q[blockIdx.y];
+  const int H = p.H, R = p.R, T = p.T, nb = gridDim.x;
+  const int u0 = blockIdx.x * P_HU;
+  const int NW = p.nw, KW = H / NW, NSL = KW / 4;    // floats per lane per row fragment (4..16, multiple of 4)
+  const long RH = (long)R * H;
+  const int GH = G * H;
+  unsigned* flg = p.flags + blockIdx.y * P_MAXB;
+  const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(q.hs);
+  if (tid == 0) s_abort = 0;
+
+  // W_hh fragments (B operand of 16x16x4: lane = column l15, k group kq), resident for all T steps.
+  // Column c = u*G + g of the block is gate row g*H + u0 + u; MFMA step s of this lane uses
+  // k = wave*KW + kq*NSL + s (the same permutation of K is applied to h below).
+  float w[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w[s] = 0.f;
+  const int kbase = wave * KW + kq * NSL;
+  if (wave < NW && l15 < NC) {
+    const int u = l15 / G, g = l15 % G;
+    const float* wr = q.W_hh + (long)(g * H + u0 + u) * H + kbase;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * j < NSL) {
+        const float4 v = *reinterpret_cast<const float4*>(wr + 4 * j);
+        w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+      }
+  }
+
+  // cell threads: (row, unit) = (tid >> 2, tid & 3); their state lives in registers
+  const bool cellt = tid < 128;
+  const int crow = tid >> 2, cu = tid & 3, cn = u0 + cu;
+  const bool crv = cellt && crow < R;
+  float hprev = 0.f, cprev = 0.f, bh[G], xa[G];
+  int64_t len = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) { bh[g] = 0.f; xa[g] = 0.f; }
+  const int init_slot = q.reverse ? T : 0;
+  if (crv) {
+    hprev = q.hs[init_slot * RH + (long)crow * H + cn];
+    if (CELL == CELL_LSTM) cprev = q.cs[init_slot * RH + (long)crow * H + cn];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bh[g] = q.b_hh[g * H + cn];
+      if (q.xadd) xa[g] = q.xadd[(long)crow * GH + g * H + cn];
+    }
+    len = q.lengths ? q.lengths[crow] : (int64_t)T;
+  }
+  __syncthreads();
+
+  for (int i = 0; i < T; ++i) {
+    const int t = q.reverse ? T - 1 - i : i;
+    const int in_slot = q.reverse ? t + 1 : t, out_slot = q.reverse ? t : t + 1;
+    // x-side pre-activations of this step: independent of the recurrence, fetched before the wait
+    float x[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) x[g] = 0.f;
+    if (crv) {
+      const float* xp = q.xproj + ((long)t * q.xmod + crow % q.xmod) * GH + cn;
+#pragma unroll
+      for (int g = 0; g < G; ++g) x[g] = xp[g * H];          // consumed after the product: no wait here
+    }
+    P_STAMP(0);
+    if (i > 0 && !wait_flags(flg, nb, (unsigned)i, p.status, &s_abort)) return;
+    P_STAMP(1);
+
+    // h_{t-1}: A operand, two 16-row fragments, this wave's K range
+    f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (wave < NW) {
+      f32x4v a[2][4];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int row = 16 * f + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[f][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          if (4 * j < NSL && row < R) a[f][j] = ld16_sc1(rs_hs, in_slot * RH + (long)row * H + kbase + 4 * j);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * j < NSL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][j][e], w[4 * j + e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][j][e], w[4 * j + e], acc[1], 0, 0, 0);
+          }
+        }
+    }
+    P_STAMP(2);
+    // C layout of 16x16x4: acc[f][r] = (row 16f + 4*kq + r, column l15)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][16 * f + 4 * kq + r][l15] = acc[f][r];
+    __syncthreads();
+    P_STAMP(3);
+
+    if (cellt) {
+      float s[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) s[g] = 0.f;
+      for (int wv = 0; wv < NW; ++wv) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[g] += red[wv][crow][cu * G + g];
+      }
+      float hnew = hprev, cnew = cprev, g0, g1, g2, g3;
+      const bool live = (int64_t)t < len;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { s[g] += bh[g]; x[g] += xa[g]; }
+      if (crv) {
+        if constexpr (CELL == CELL_GRU) {
+          const float rg = sigmoidf_(x[0] + s[0]);
+          const float zg = sigmoidf_(x[1] + s[1]);
+          const float nn = tanhf_(x[2] + rg * s[2]);
+          if (live) hnew = (1.f - zg) * nn + zg * hprev;
+          g0 = rg; g1 = zg; g2 = nn; g3 = s[2];
+        } else {
+          const float ig = sigmoidf_(x[0] + s[0]);
+          const float fg = sigmoidf_(x[1] + s[1]);
+          const float gg = tanhf_(x[2] + s[2]);
+          const float og = sigmoidf_(x[3] + s[3]);
+          const float cc = fg * cprev + ig * gg;
+          if (live) { hnew = og * tanhf_(cc); cnew = cc; }
+          g0 = ig; g1 = fg; g2 = gg; g3 = og;
+        }
+      } else {
+        g0 = g1 = g2 = g3 = 0.f;
+      }
+      hprev = hnew; cprev = cnew;
+      // gather the 4 units of a row into the lane of unit 0: 16-byte stores
+      f32x4v hv, cv, gv[4];
+      hv[0] = hnew; cv[0] = cnew; gv[0][0] = g0; gv[1][0] = g1; gv[2][0] = g2; gv[3][0] = g3;
+#pragma unroll
+      for (int d = 1; d < 4; ++d) {
+        hv[d] = __shfl_down(hnew, d, 64);
+        cv[d] = __shfl_down(cnew, d, 64);
+        gv[0][d] = __shfl_down(g0, d, 64); gv[1][d] = __shfl_down(g1, d, 64);
+        gv[2][d] = __shfl_down(g2, d, 64); gv[3][d] = __shfl_down(g3, d, 64);
+      }
+      if (crv && cu == 0) {
+        const long o = (long)crow * H + u0;
+        st16_sc1(rs_hs, out_slot * RH + o, hv);                                   // the hand-off payload
+        if (CELL == CELL_LSTM) *reinterpret_cast<f32x4v*>(q.cs + out_slot * RH + o) = cv;
+        if (q.gates) {
+          float* gp = q.gates + ((long)t * R + crow) * 4 * H + u0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4v*>(gp + g * H) = gv[g];
+        }
+      }
+    }
+    P_STAMP(4);
+    publish(flg, (unsigned)(i + 1));
+    P_STAMP(5);
+  }
+  if (stamp_on)
+    for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
+}
+
+// -------------------------------------------------------------------------------------- backward
+template <int CELL>
+__global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];      // Wl[4][GH + 4] | red[16][32][4]
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 31, kh = lane >> 5, jc = lane & 3;
+  const PSeqB& q = p.q[blockIdx.y];
+  const int H = p.H, R = p.R, T = p.T, nb = gridDim.x;
+  const int GH = G * H, LDW = GH + 4;
+  const int u0 = blockIdx.x * P_HU;
+  const long RH = (long)R * H;
+  float* Wl = dyn;
+  float* red = dyn + 4 * LDW;
+  unsigned* flg = p.flags + blockIdx.y * P_MAXB;
+  const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float* dgh_base = q.dgh ? q.dgh : q.dgx;
+  const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(dgh_base);
+  if (tid == 0) s_abort = 0;
+
+  // W_hh[:, u0..u0+3] -> Wl[j][c]
+  for (int c = tid; c < GH; c += P_THREADS) {
+    const float4 v = *reinterpret_cast<const float4*>(q.W_hh + (long)c * H + u0);
+    Wl[0 * LDW + c] = v.x; Wl[1 * LDW + c] = v.y; Wl[2 * LDW + c] = v.z; Wl[3 * LDW + c] = v.w;
+  }
+  const int KW = GH / 16, NL = KW / 2;               // K per wave; floats per lane (multiple of 4, <= 64)
+  const int kbase = wave * KW + kh * NL;
+
+  const bool cellt = tid < 128;
+  const int crow = tid >> 2, cu = tid & 3, cn = u0 + cu;
+  const bool crv = cellt && crow < R;
+  float dh_carry = 0.f, dc = 0.f;
+  int64_t len = 0;
+  if (crv) {
+    if (q.dh_last) dh_carry = q.dh_last[(long)crow * H + cn];
+    if (CELL == CELL_LSTM && q.dc_last) dc = q.dc_last[(long)crow * H + cn];
+    len = q.lengths ? q.lengths[crow] : (int64_t)T;
+  }
+  __syncthreads();
+
+  // dG_{t_src}[32 x GH] . W_hh[:, 4 units] -> this thread's (crow, cu) element (cell threads)
+  auto product = [&](int t_src) -> float {
+    f32x4v acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const long abase = ((long)t_src * R + row) * GH + kbase;
+    const float* wl = Wl + jc * LDW + kbase;
+    f32x4v a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      a[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (4 * j < NL && row < R) a[j] = ld16_sc1(rs_dgh, abase + 4 * j);
+    }
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P_STAMP(6); }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (4 * j < NL) {
+        const f32x4v b = *reinterpret_cast<const f32x4v*>(wl + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][e], b[e], acc[e], 0, 0, 0);
+      }
+    f32x4v sum = acc[0] + acc[1] + acc[2] + acc[3];
+    if (p.stamps) { asm volatile("s_nop 0" : "+v"(sum)); P_STAMP(7); }
+    // lane = (block, column jc): block = row group (lane/4 % 8) + 8 * K half; register i = row in group
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], 32, 64);
+    if (kh == 0) {
+      const int rg = (lane >> 2) & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(wave * 32 + 4 * rg + i) * 4 + jc] = sum[i];
+    }
+    __syncthreads();
+    P_STAMP(8);
+    float tot = 0.f;
+    if (cellt) {
+#pragma unroll
+      for (int wv = 0; wv < 16; ++wv) tot += red[(wv * 32 + crow) * 4 + cu];
+    }
+    return tot;
+  };
+
+  for (int i = T - 1; i >= 0; --i) {
+    const int t = q.reverse ? T - 1 - i : i;
+    const int in_slot = q.reverse ? t + 1 : t, out_slot = q.reverse ? t : t + 1;
+    // saved tensors of step t for this (row, unit): independent of the recurrence
+    float gl[4] = {0.f, 0.f, 0.f, 0.f}, hin = 0.f, cin = 0.f, cout = 0.f, dhs_t = 0.f;
+    if (crv) {
+      const float* gp = q.gates + ((long)t * R + crow) * 4 * H + cn;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gl[g] = gp[g * H];
+      hin = q.hs[in_slot * RH + (long)crow * H + cn];
+      if (CELL == CELL_LSTM) {
+        cin = q.cs[in_slot * RH + (long)crow * H + cn];
+        cout = q.cs[out_slot * RH + (long)crow * H + cn];
+      }
+      if (q.dhs) dhs_t = q.dhs[(long)t * RH + (long)crow * H + cn];
+    }
+    float part = 0.f;
+    P_STAMP(0);
+    if (i < T - 1) {
+      if (!wait_flags(flg, nb, (unsigned)(T - 1 - i), p.status, &s_abort)) return;
+      P_STAMP(1);
+      part = product(q.reverse ? t - 1 : t + 1);
+      P_STAMP(3);
+    }
+    if (cellt) {
+      float ox[4] = {0.f, 0.f, 0.f, 0.f}, oh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (crv) {
+        const bool live = (int64_t)t < len;
+        const float dh = dh_carry + dhs_t + part;
+        dh_carry = cell_bwd_point<CELL>(live, dh, dc, gl, 1, hin, cin, cout, ox, CELL == CELL_GRU ? oh : nullptr);
+      }
+      // 16-byte stores per (row, gate): gather the 4 units into the lane of unit 0
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4v vx, vh;
+        vx[0] = ox[g]; vh[0] = oh[g];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+          vx[d] = __shfl_down(ox[g], d, 64);
+          if (CELL == CELL_GRU) vh[d] = __shfl_down(oh[g], d, 64);
+        }
+        if (crv && cu == 0) {
+          const long o = ((long)t * R + crow) * GH + g * H + u0;
+          if (CELL == CELL_GRU) {
+            *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
+            st16_sc1(rs_dgh, o, vh);                 // h-side gradients: the hand-off payload
+          } else {
+            st16_sc1(rs_dgh, o, vx);                 // LSTM: x side == h side (normally one buffer)
+            if (q.dgx != dgh_base) *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
+          }
+        }
+      }
+    }
+    P_STAMP(4);
+    publish(flg, (unsigned)(T - i));
+    P_STAMP(5);
+  }
+  // gradient wrt the initial state: carry + product with the first step's dG
+  float part = 0.f;
+  if (T > 0) {
+    if (!wait_flags(flg, nb, (unsigned)T, p.status, &s_abort)) return;
+    part = product(q.reverse ? T - 1 : 0);
+  }
+  if (crv) {
+    q.dh0[(long)crow * H + cn] = dh_carry + part;
+    if (CELL == CELL_LSTM) q.dc0[(long)crow * H + cn] = dc;
+  }
+  if (stamp_on)
+    for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
+}
+
+// ------------------------------------------------------------------------------------ host side
+// library-owned sync words: [SKINNY_MAX_BATCH][P_MAXB] epoch flags | 16 status words | 16 stamp accumulators
+constexpr int P_FLAG_WORDS = SKINNY_MAX_BATCH * P_MAXB;
+static unsigned* g_sync = nullptr;
+static int g_stamps_on = -1;
+static int persist_sync(unsigned** out) {
+  if (!g_sync) {
+    const size_t bytes = (size_t)(P_FLAG_WORDS + 16) * 4 + 16 * 8;
+    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_sync), bytes), "persist sync words"));
+    CVAE_TRY(check_hip(hipMemset(g_sync, 0, bytes), "persist sync memset"));
+    const char* e = getenv("CVAE_PERSIST_STAMPS");
+    g_stamps_on = (e && e[0] == '1') ? 1 : 0;
+  }
+  *out = g_sync;
+  return 0;
+}
+static unsigned long long* persist_stamps() {
+  return g_stamps_on == 1 ? reinterpret_cast<unsigned long long*>(g_sync + P_FLAG_WORDS + 16) : nullptr;
+}
+
+static int persist_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVAE_PERSISTENT_RNN");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on;
+}
+
+static int cu_count() {
+  static int cus = 0;
+  if (!cus) cus = persistent_grid_blocks() / 2;
+  return cus;
+}
+
+bool rnn_persist_supported(int cell, int T, int R, int H, int ns) {
+  if (!persist_enabled() || T < 1 || R < 1 || R > 32 || ns < 1 || ns > SKINNY_MAX_BATCH) return false;
+  if (H % 128 != 0 || H > 512) return false;
+  return H / P_HU <= P_MAXB && (H / P_HU) * ns <= cu_count();
+}
+
+int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s) {
+  unsigned* sync = nullptr;
+  CVAE_TRY(persist_sync(&sync));
+  CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
+  PFwdArgs p = {};
+  p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
+  p.nw = 0;
+  for (int nw = 16; nw >= 2 && !p.nw; nw >>= 1)                        // K per wave: multiple of 16, <= 64
+    if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
+  CVAE_REQUIRE(p.nw >= 1 && p.nw <= 16 && p.H % p.nw == 0 && (p.H / p.nw) % 16 == 0 && p.H / p.nw <= 64,
+               "rnn_forward_persist: H=%d does not split over the block's waves", p.H);
+  p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
+  for (int k = 0; k < ns; ++k) {
+    const RnnFwd& r = a[k];
+    CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.hs) & 15) == 0 && (!r.cs || (reinterpret_cast<uintptr_t>(r.cs) & 15) == 0) &&
+                 (!r.gates || (reinterpret_cast<uintptr_t>(r.gates) & 15) == 0) &&
+                 (reinterpret_cast<uintptr_t>(r.W_hh) & 15) == 0, "rnn_forward_persist: operands must be 16-byte aligned");
+    p.q[k] = PSeqF{r.xproj, r.xadd, r.W_hh, r.b_hh, r.lengths, r.hs, r.cs, r.gates, r.xmod, r.reverse};
+  }
+  const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
+  ProfScope prof(PK_SKINNY, s, 2.0 * ns * p.T * p.R * (a[0].cell == CELL_GRU ? 3.0 : 4.0) * p.H * p.H);
+  if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_GRU>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_LSTM>, grid, block, 0, s, p);
+  CVAE_LAUNCH_CHECK("rnn_fwd_persist_kernel");
+  return 0;
+}
+
+bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVAE_PERSISTENT_RNN_BWD");
+    on = (e && e[0] == '1') ? 1 : 0;      // opt-in: the one-launch-per-step path is faster for now
+  }
+  return on && rnn_persist_supported(cell, T, R, H, ns);
+}
+
+int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
+  unsigned* sync = nullptr;
+  CVAE_TRY(persist_sync(&sync));
+  CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
+  PBwdArgs p = {};
+  p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
+  p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
+  const int G = a[0].cell == CELL_GRU ? 3 : 4;
+  const int GH = G * p.H;
+  CVAE_REQUIRE(GH % 128 == 0 && GH / 32 <= 64, "rnn_backward_persist: G*H=%d does not split over the block's waves", GH);
+  for (int k = 0; k < ns; ++k) {
+    const RnnBwd& r = a[k];
+    float* dgh = r.dgh ? r.dgh : r.dgx;
+    CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(r.W_hh) & 15) == 0, "rnn_backward_persist: operands must be 16-byte aligned");
+    p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse};
+  }
+  const size_t lds = (size_t)(4 * (GH + 4) + 16 * 32 * 4) * sizeof(float);
+  const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
+  ProfScope prof(PK_SKINNY, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
+  if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_GRU>, grid, block, lds, s, p);
+  else hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_LSTM>, grid, block, lds, s, p);
+  CVAE_LAUNCH_CHECK("rnn_bwd_persist_kernel");
+  return 0;
+}
+
+// Synchronises the device and reports (then clears) the timeout word of the persistent kernels.
+int persist_status_and_clear() {
+  if (!g_sync) return 0;
+  int st = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&st, g_sync + P_FLAG_WORDS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (st && hipMemset(g_sync + P_FLAG_WORDS, 0, sizeof(int)) != hipSuccess) return -1;
+  if (g_stamps_on == 1) {
+    unsigned long long acc[16];
+    if (hipMemcpy(acc, persist_stamps(), sizeof(acc), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "[cvae persist stamps, cycles of block (0,0)] loop-top->wait %llu | wait %llu | load+mfma %llu | reduce %llu | "
+              "cell+stores %llu | drain+flag %llu || bwd product: loads %llu | mfma %llu | shfl+sync %llu\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8]);
+      if (hipMemset(persist_stamps(), 0, sizeof(acc)) != hipSuccess) return -1;
+    }
+  }
+  return st;
+}
+
+}  // namespace cvae

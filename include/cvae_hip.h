@@ -195,6 +195,10 @@ int cvae_profile_enable(int on);
 int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_work);
 
 /* small helpers used by the host mirror */
+/* Synchronises the device and returns (then clears) the timeout word of the whole-sequence
+ * recurrent kernels: 0 = every in-kernel wait completed; 1 = a bounded spin ran out (results of
+ * that call are invalid).  No counterpart in the reference (torch's cuDNN RNN has no such state). */
+int cvae_persist_status(void);
 int cvae_sum_time(const float* x, int T, int R, float* out, void* stream);       /* out[r] = sum_t x[t,r] */
 int cvae_axpy(const float* x, float a, int64_t n, float* y, void* stream);       /* y += a*x */
 

@@ -34,6 +34,9 @@ def bench_gemm():
         ('xproj     NT  6400x1024x200', 6400, 1024, 200, 0, 1),
         ('dWih      TN  1024x200x6400', 1024, 200, 6400, 1, 0),
         ('dxin      NN  6400x200x1024', 6400, 200, 1024, 0, 0),
+        ('eval hWhh NT 16000x1024x256', 16000, 1024, 256, 0, 1),
+        ('eval hWhh NT 16000x768x256', 16000, 768, 256, 0, 1),
+        ('eval Wc   NT 16000x200x256', 16000, 200, 256, 0, 1),
     ]
     for lab, M, N, K, ta, tb in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev)

@@ -116,7 +116,8 @@ def _rnn_params(cell, inp, hid, bi, seed):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
-@pytest.mark.parametrize('shape', [(5, 7, 16, 8, 50), (32, 40, 200, 128, 1000)])
+# H = 8: per-step kernels; H = 128 / 256 with B <= 32: whole-sequence kernels (rnn_persist.hip), ragged rows
+@pytest.mark.parametrize('shape', [(5, 7, 16, 8, 50), (32, 40, 200, 128, 1000), (19, 23, 40, 256, 300)])
 def test_encoder_forward_backward(dev, cell, shape):
     """Packed bi-RNN last states + every gradient vs the oracle in fp64."""
     from cvae_amd import ops
@@ -160,7 +161,7 @@ def test_encoder_forward_backward(dev, cell, shape):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
-@pytest.mark.parametrize('shape', [(5, 8, 16, 16, 50), (32, 30, 200, 256, 1000)])
+@pytest.mark.parametrize('shape', [(5, 8, 16, 16, 50), (32, 30, 200, 256, 1000), (13, 17, 24, 512, 200)])
 def test_decoder_forward_backward(dev, cell, shape):
     from cvae_amd import ops
     B, T, E, Hd, V = shape
