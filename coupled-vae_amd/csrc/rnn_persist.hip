@@ -21,7 +21,11 @@
 //     payload stored write-through (`sc1` buffer stores), every storing wave drains (vmcnt(0)),
 //     workgroup barrier, ONE lane adds to the sequence's agent-scope counter; consumers poll that
 //     counter with `sc1` loads (one lane, bounded), barrier, then read the payload with `sc1`
-//     buffer loads.  Every spin is bounded: on a timeout the block raises the status word and the
+//     buffer loads.  (Tried and dropped: data-tagged {value, epoch} granules polled directly by the
+//     consumer waves.  16-byte sc1 buffer loads re-reading a line that had been polled before the
+//     store landed kept returning the old copy; 8-byte agent-scope loads were correct but 2x slower
+//     than flag + 16-byte payload loads, and 2000 polling waves slowed the producers' stores.)
+//     Every spin is bounded: on a timeout the block raises the status word and the
 //     whole grid drains (cvae_persist_status reports it).
 #include "common.hpp"
 #include "cell_math.hpp"
@@ -112,10 +116,15 @@ __device__ __forceinline__ void publish(unsigned* flags, unsigned epoch) {
   do {                                                                             \
     if (stamp_on) {                                                                \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
-      sacc_[k] += now_ - tprev_;                                                   \
+      sacc_[k] += (unsigned)(now_ - tprev_);                                       \
       tprev_ = now_;                                                               \
     }                                                                              \
   } while (0)
+
+// Activations of the in-kernel cell: v_exp_f32 + v_rcp_f32 (absolute error ~3e-7, far inside the
+// 1e-4 parity bar); the cell sits on the per-step critical path, libm's tanhf alone is ~60 instructions.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // --------------------------------------------------------------------------------------- forward
 template <int CELL>
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
   unsigned* flg = p.flags + blockIdx.y * P_MAXB;
   const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
-  unsigned long long sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // cycles fit 32 bits for one launch
   const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(q.hs);
   if (tid == 0) s_abort = 0;
 
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
     }
     len = q.lengths ? q.lengths[crow] : (int64_t)T;
   }
+  const int xrow = crv ? crow % q.xmod : 0;
   __syncthreads();
 
   for (int i = 0; i < T; ++i) {
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
 #pragma unroll
     for (int g = 0; g < G; ++g) x[g] = 0.f;
     if (crv) {
-      const float* xp = q.xproj + ((long)t * q.xmod + crow % q.xmod) * GH + cn;
+      const float* xp = q.xproj + ((long)t * q.xmod + xrow) * GH + cn;
 #pragma unroll
       for (int g = 0; g < G; ++g) x[g] = xp[g * H];          // consumed after the product: no wait here
     }
@@ -240,18 +250,18 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
       for (int g = 0; g < G; ++g) { s[g] += bh[g]; x[g] += xa[g]; }
       if (crv) {
         if constexpr (CELL == CELL_GRU) {
-          const float rg = sigmoidf_(x[0] + s[0]);
-          const float zg = sigmoidf_(x[1] + s[1]);
-          const float nn = tanhf_(x[2] + rg * s[2]);
+          const float rg = fast_sigmoid(x[0] + s[0]);
+          const float zg = fast_sigmoid(x[1] + s[1]);
+          const float nn = fast_tanh(x[2] + rg * s[2]);
           if (live) hnew = (1.f - zg) * nn + zg * hprev;
           g0 = rg; g1 = zg; g2 = nn; g3 = s[2];
         } else {
-          const float ig = sigmoidf_(x[0] + s[0]);
-          const float fg = sigmoidf_(x[1] + s[1]);
-          const float gg = tanhf_(x[2] + s[2]);
-          const float og = sigmoidf_(x[3] + s[3]);
+          const float ig = fast_sigmoid(x[0] + s[0]);
+          const float fg = fast_sigmoid(x[1] + s[1]);
+          const float gg = fast_tanh(x[2] + s[2]);
+          const float og = fast_sigmoid(x[3] + s[3]);
           const float cc = fg * cprev + ig * gg;
-          if (live) { hnew = og * tanhf_(cc); cnew = cc; }
+          if (live) { hnew = og * fast_tanh(cc); cnew = cc; }
           g0 = ig; g1 = fg; g2 = gg; g3 = og;
         }
       } else {
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   unsigned* flg = p.flags + blockIdx.y * P_MAXB;
   const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
-  unsigned long long sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // cycles fit 32 bits for one launch
   const float* dgh_base = q.dgh ? q.dgh : q.dgx;
   const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(dgh_base);
   if (tid == 0) s_abort = 0;
