@@ -35,7 +35,8 @@ import torch.distributed as dist   # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
-           3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_fwd_kernel', 'mfma')}
+           3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
+           6: ('rnn_persist_kernel', 'mfma')}
 
 
 def parse():
@@ -77,6 +78,21 @@ def profile_read(lib):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from
+    inside this process, so the figure is the recorded one for the same workload, or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_summary.json')
+    if kernel != 'ce_core_kernel' or not os.path.exists(path):
+        return None
+    try:
+        rec = json.load(open(path))['ce_core_forward_eval_launch']
+        return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
+    except (KeyError, ValueError):
+        return None
+
+
 def roofline_of(prof):
     """The kernel with the largest total time in the profiled pass."""
     name, rec = max(prof.items(), key=lambda kv: kv[1]['ms'])
@@ -88,7 +104,7 @@ def roofline_of(prof):
     else:
         ach, peak, unit = per_s / 1e9, PEAK_HBM_GBS, 'GB/s'
     return dict(kernel=name, bound=rec['bound'], achieved=round(ach, 3), peak=peak, unit=unit,
-                frac=round(ach / peak, 4), traffic=None, launches=rec['launches'],
+                frac=round(ach / peak, 4), traffic=pmc_traffic(name), launches=rec['launches'],
                 avg_launch_ms=round(rec['ms'] / rec['launches'], 5),
                 work_per_launch=rec['work'] / rec['launches'])
 

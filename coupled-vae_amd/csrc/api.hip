@@ -45,6 +45,8 @@ static bool prof_event(hipEvent_t* e) {
   return true;
 }
 
+bool prof_enabled() { return g_prof_on; }
+
 ProfScope::ProfScope(int kernel, hipStream_t stream, double work) : slot(-1), s(stream) {
   if (!g_prof_on || g_prof.size() >= kProfMaxRecs) return;
   ProfRec r;

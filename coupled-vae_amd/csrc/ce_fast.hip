@@ -382,6 +382,16 @@ static int launch_core(const CeArgs& a, hipStream_t s) {
   return 0;
 }
 
+// Profiling mode only (bench.py's roofline leg): the live-row count, so that the recorded work is
+// the ALGORITHMIC one (rows that are multiplied), not the padded N.  Synchronises the stream.
+static long live_rows_for_profile(const int* nlive, long N, hipStream_t s) {
+  if (!prof_enabled()) return N;
+  int h = 0;
+  if (hipStreamSynchronize(s) != hipSuccess) return N;
+  if (hipMemcpy(&h, nlive, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return N;
+  return h;
+}
+
 // X [nseg*TR, E]; tgt [TR]; loss, lse [nseg*TR]
 int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
                            long N, long TR, int E, int V, float* loss, float* lse, float* ws, hipStream_t s) {
@@ -400,7 +410,8 @@ int launch_ce_fast_forward(const float* X, const float* W, const float* bias, co
   a.cap = cap; a.pstride = N; a.tl = tl; a.pm = tl + N; a.ps = a.pm + (long)cap * N;
   CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, loss, lse, tl, s));
   {
-    ProfScope prof(PK_CE_FWD, s, 2.0 * N * E * V);
+    const long live = live_rows_for_profile(nlive, N, s);
+    ProfScope prof(PK_CE_FWD, s, 2.0 * live * E * V);
     CVAE_TRY(launch_core<false>(a, s));
   }
   hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, persistent_grid_blocks(), loss, lse);
@@ -452,21 +463,25 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
   a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
   a.vec = aligned16(X) && aligned16(W) && (E % 4 == 0);
   a.cap = 64; a.lse = lse; a.gsent = gsent; a.R = R; a.P = P; a.ldp = ldp;
+  const long live = live_rows_for_profile(nlive, N, s);
   for (long r0 = 0; r0 < N; r0 += CH) {
     const int rc = (int)((N - r0) < CH ? (N - r0) : CH);
+    long lrc = live - r0;                    // live rows of this chunk (profiling: exact; else the bound)
+    if (lrc > rc) lrc = rc;
+    if (lrc < 0) lrc = 0;
     a.r0 = (int)r0; a.rcount = rc;
     {
-      ProfScope prof(PK_CE_FWD, s, 2.0 * rc * E * V);
+      ProfScope prof(PK_CE_FWD, s, 2.0 * lrc * E * V);
       CVAE_TRY(launch_core<true>(a, s));
     }
     G224Args gx = {};      // dX[rows[r0+m], :] += P[m, :] . W
     gx.A = P; gx.lda = ldp; gx.B = W; gx.ldb = E; gx.C = dX; gx.ldc = E;
-    gx.M = rc; gx.N = E; gx.K = V; gx.nlive = nlive; gx.r0 = (int)r0; gx.dev_bound = 1; gx.rows = rows; gx.part = part;
+    gx.M = rc; gx.N = E; gx.K = V; gx.nlive = nlive; gx.r0 = (int)r0; gx.dev_bound = 1; gx.rows = rows; gx.part = part; gx.prof_units = lrc;
     CVAE_TRY(launch_gemm_wide(true, gx, s));
     G224Args gw = {};      // [dW | db] += P^T . [X[rows[r0+k], :] | 1]
     gw.A = P; gw.lda = ldp; gw.B = X; gw.ldb = E; gw.C = dW; gw.ldc = E;
     gw.M = V; gw.N = E; gw.K = rc; gw.nlive = nlive; gw.r0 = (int)r0; gw.dev_bound = 2; gw.rows = rows;
-    gw.extra = db; gw.beta = 1; gw.part = part;
+    gw.extra = db; gw.beta = 1; gw.part = part; gw.prof_units = lrc;
     CVAE_TRY(launch_gemm_wide(false, gw, s));
   }
   return 0;

@@ -33,13 +33,16 @@ int check_hip(hipError_t e, const char* what);
 
 // ---- opt-in per-kernel timing (bench.py's roofline leg): HIP events recorded on the launch
 // stream around the kernels named below.  Off by default: no events, no overhead.
-enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_COUNT = 5 };
+enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_GEMM_WIDE = 5,
+                  PK_RNN_PERSIST = 6, PK_COUNT = 7 };
 struct ProfScope {
   int slot;
   hipStream_t s;
   ProfScope(int kernel, hipStream_t stream, double work);   // work: algorithmic FLOPs (MFMA kernels) or bytes
   ~ProfScope();
 };
+
+bool prof_enabled();   // true while cvae_profile_enable(1) is in effect
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -101,6 +104,7 @@ struct G224Args {
   float* extra;               // optional [M]: extra[m] (+)= sum_k A[m,k] (a ones column appended to B; N <= 220)
   int beta;                   // 0: C (and extra) overwritten, 1: accumulated into
   float* part;                // partial-sum slabs (gemm_wide_part_floats); null -> library scratch
+  long prof_units;            // profiling: live extent of the device-bounded dimension (0: use the host bound)
   int ntiles, tile_w, part_ld;   // filled by the launcher
   int vecA, vecB, vecC;
 };

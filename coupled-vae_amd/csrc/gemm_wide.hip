@@ -311,7 +311,10 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   const int nblk = persistent_grid_blocks();
   const dim3 grid(nblk), block(256);
   {
-    ProfScope prof(PK_GEMM_TILED, s, 2.0 * a.M * a.N * a.K);
+    double pm = a.M, pk = a.K;
+    if (a.dev_bound == 1 && a.prof_units > 0) pm = (double)a.prof_units;
+    if (a.dev_bound == 2 && a.prof_units > 0) pk = (double)a.prof_units;
+    ProfScope prof(PK_GEMM_WIDE, s, 2.0 * pm * a.N * pk);
     if (akc) {
       if (wide) hipLaunchKernelGGL((gemm_wide_kernel<true, 7>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, block, 0, s, a);

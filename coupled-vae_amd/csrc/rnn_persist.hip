@@ -513,7 +513,7 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s) {
     p.q[k] = PSeqF{r.xproj, r.xadd, r.W_hh, r.b_hh, r.lengths, r.hs, r.cs, r.gates, r.xmod, r.reverse};
   }
   const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
-  ProfScope prof(PK_SKINNY, s, 2.0 * ns * p.T * p.R * (a[0].cell == CELL_GRU ? 3.0 : 4.0) * p.H * p.H);
+  ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * (a[0].cell == CELL_GRU ? 3.0 : 4.0) * p.H * p.H);
   if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_GRU>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_LSTM>, grid, block, 0, s, p);
   CVAE_LAUNCH_CHECK("rnn_fwd_persist_kernel");
@@ -548,7 +548,7 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   }
   const size_t lds = (size_t)(4 * (GH + 4) + 16 * 32 * 4) * sizeof(float);
   const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
-  ProfScope prof(PK_SKINNY, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
+  ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
   if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_GRU>, grid, block, lds, s, p);
   else hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_LSTM>, grid, block, lds, s, p);
   CVAE_LAUNCH_CHECK("rnn_bwd_persist_kernel");
