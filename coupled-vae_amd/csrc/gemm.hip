@@ -173,7 +173,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
   }
   // Long-K products with a k-major B and at most a few hundred columns (weight gradients over
   // T*B rows, input gradients): persistent split-K kernel of gemm_wide.hip.
-  if (!d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= 448 && d.M >= 64) {
+  if (!d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= 1024 && d.M >= 64) {
     G224Args w = {};
     w.A = d.A; w.lda = d.lda; w.B = d.B; w.ldb = d.ldb; w.C = d.C; w.ldc = d.ldc;
     w.M = d.M; w.N = d.N; w.K = d.K; w.beta = d.beta;

@@ -51,6 +51,8 @@ GEMM_CASES = [
     (333, 131, 517, 0, 0, 0, 0, 0),        # ragged M/N/K, 224-wide tile with 131 live columns
     (70, 447, 600, 1, 0, 0, 0, 0),         # two 224-wide tiles, unaligned N
     (6432, 200, 1024, 0, 0, 0, 0, 0),      # dX = dG W_ih
+    (2048, 512, 3000, 1, 0, 0, 0, 0),      # decoder dW_hh: four 128-column tiles
+    (200, 512, 3000, 1, 0, 0, 0, 1),       # dW_c accumulate
 ]
 
 
