@@ -67,6 +67,7 @@ struct PBwdArgs {
   unsigned* flags;
   int* status;
   unsigned long long* stamps;
+  float* exch;                       // [ns][2][nb][nb][32][4] partial-sum exchange
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -104,7 +105,9 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int nb, unsign
   return *s_abort == 0;
 }
 
-// Every storing wave has drained; one lane raises this block's flag (sc1 store).
+// Every storing wave has drained; one lane raises this block's flag (sc1 store).  (Raising it from
+// the last wave instead, to keep wave 0's back-edge vmcnt drain off the flag store, made the flag
+// later for everyone else: +15 % per step.  Lane 0 it is.)
 __device__ __forceinline__ void publish(unsigned* flags, unsigned epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -298,35 +301,56 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
 }
 
 // -------------------------------------------------------------------------------------- backward
+// Step t of the backward recurrence, for the block that owns hidden units U (4 units, 4G gate rows):
+//   1. dh_t[:, U] = carry + dhs_t[:, U] + sum over ALL blocks b of part_b[:, U]   (read the exchange)
+//   2. cell backward for (row, unit in U)  ->  dG_t[:, gate rows of U]  (global, for the weight
+//      gradients; and LDS, as the A operand of the next product)
+//   3. part[32 x H] = dG_t[:, rows of U] (32 x 4G) . W_hh[rows of U, :] (4G x H): the block's K-slice
+//      of dh_{t-1} for EVERY unit.  v_mfma_f32_16x16x4_f32, W slice in registers, no padding waste
+//      (owning output columns instead would leave a 32 x 4 tile per block: 4x MFMA padding, and an
+//      all-gather of the 32 x G*H gradient, 256 KB per block per step - measured 12 us per step).
+//   4. publish part, destination-major: ex[dest block][this block][32 rows][4 units] (sc1 16-byte
+//      stores), drain, flag.  The destination reads one contiguous nb x 512 B run.
+// Two exchange buffers (step parity).  Deterministic: partials are summed in block order.
 template <int CELL>
 __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
-  extern __shared__ __attribute__((aligned(16))) float dyn[];      // Wl[4][GH + 4] | red[16][32][4]
+  constexpr int NC = P_HU * G;                       // live K of this block's slice (12 / 16)
+  extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[32][H + 4]  (aliased: red[32][32][4])
+  __shared__ __attribute__((aligned(16))) float dGl[32][16];       // dG of this block: [row][u*G + g]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = lane & 31, kh = lane >> 5, jc = lane & 3;
+  const int l15 = lane & 15, kq = lane >> 4;
   const PSeqB& q = p.q[blockIdx.y];
   const int H = p.H, R = p.R, T = p.T, nb = gridDim.x;
-  const int GH = G * H, LDW = GH + 4;
+  const int GH = G * H, LDT = H + 4;
   const int u0 = blockIdx.x * P_HU;
   const long RH = (long)R * H;
-  float* Wl = dyn;
-  float* red = dyn + 4 * LDW;
+  float* tile = dyn;
+  float* red = dyn;
   unsigned* flg = p.flags + blockIdx.y * P_MAXB;
   const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
-  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // cycles fit 32 bits for one launch
-  const float* dgh_base = q.dgh ? q.dgh : q.dgx;
-  const __amdgpu_buffer_rsrc_t rs_dgh = make_rsrc(dgh_base);
+  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float* dgh_base = q.dgh ? q.dgh : q.dgx;
+  // exchange: [parity][dest][src][32][4] floats
+  const long ex_par = (long)nb * nb * 128;
+  const __amdgpu_buffer_rsrc_t rs_ex = make_rsrc(p.exch + (size_t)blockIdx.y * 2 * ex_par);
   if (tid == 0) s_abort = 0;
+  for (int i = tid; i < 32 * 16; i += P_THREADS) (&dGl[0][0])[i] = 0.f;
 
-  // W_hh[:, u0..u0+3] -> Wl[j][c]
-  for (int c = tid; c < GH; c += P_THREADS) {
-    const float4 v = *reinterpret_cast<const float4*>(q.W_hh + (long)c * H + u0);
-    Wl[0 * LDW + c] = v.x; Wl[1 * LDW + c] = v.y; Wl[2 * LDW + c] = v.z; Wl[3 * LDW + c] = v.w;
-  }
-  const int KW = GH / 16, NL = KW / 2;               // K per wave; floats per lane (multiple of 4, <= 64)
-  const int kbase = wave * KW + kh * NL;
+  // W_hh[gate rows of U, :] as B fragments: wave w owns output column fragments w, w + 16, ...
+  // (H / 16 fragments); fragment nf, MFMA step s: lane (n = l15, kq) holds W_hh[row(4s + kq)][16*nf + l15]
+  const int nfr = H / 16;
+  float w[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int nf = wave + 16 * j, k = 4 * s + kq;
+      w[j][s] = 0.f;
+      if (nf < nfr && k < NC) w[j][s] = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+    }
 
   const bool cellt = tid < 128;
   const int crow = tid >> 2, cu = tid & 3, cn = u0 + cu;
@@ -340,44 +364,30 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   }
   __syncthreads();
 
-  // dG_{t_src}[32 x GH] . W_hh[:, 4 units] -> this thread's (crow, cu) element (cell threads)
-  auto product = [&](int t_src) -> float {
-    f32x4v acc[4];
+  // sum over all source blocks of their partial for (crow, cu); parity = buffer to read
+  auto gather = [&](int parity) -> float {
+    const long base = (long)parity * ex_par + (long)blockIdx.x * nb * 128;
+    // piece p = src * 32 + row; this thread takes p = tid, tid + 1024, ...
+    f32x4v sum = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int npieces = nb * 32;
+    f32x4v v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const long abase = ((long)t_src * R + row) * GH + kbase;
-    const float* wl = Wl + jc * LDW + kbase;
-    f32x4v a[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      a[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      if (4 * j < NL && row < R) a[j] = ld16_sc1(rs_dgh, abase + 4 * j);
+    for (int j = 0; j < 4; ++j) {
+      v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      const int pc = tid + P_THREADS * j;
+      if (pc < npieces) v[j] = ld16_sc1(rs_ex, base + (long)pc * 4);
     }
-    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P_STAMP(6); }
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (4 * j < NL) {
-        const f32x4v b = *reinterpret_cast<const f32x4v*>(wl + 4 * j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][e], b[e], acc[e], 0, 0, 0);
-      }
-    f32x4v sum = acc[0] + acc[1] + acc[2] + acc[3];
-    if (p.stamps) { asm volatile("s_nop 0" : "+v"(sum)); P_STAMP(7); }
-    // lane = (block, column jc): block = row group (lane/4 % 8) + 8 * K half; register i = row in group
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], 32, 64);
-    if (kh == 0) {
-      const int rg = (lane >> 2) & 7;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) red[(wave * 32 + 4 * rg + i) * 4 + jc] = sum[i];
-    }
+    for (int j = 0; j < 4; ++j) sum += v[j];
+    // red[group = tid >> 5][row = tid & 31][4]
+    *reinterpret_cast<f32x4v*>(red + (size_t)tid * 4) = sum;
     __syncthreads();
-    P_STAMP(8);
     float tot = 0.f;
     if (cellt) {
-#pragma unroll
-      for (int wv = 0; wv < 16; ++wv) tot += red[(wv * 32 + crow) * 4 + cu];
+#pragma unroll 8
+      for (int g = 0; g < 32; ++g) tot += red[((size_t)g * 32 + crow) * 4 + cu];
     }
+    __syncthreads();                                  // red is aliased with the product tile
     return tot;
   };
 
@@ -402,8 +412,8 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     if (i < T - 1) {
       if (!wait_flags(flg, nb, (unsigned)(T - 1 - i), p.status, &s_abort)) return;
       P_STAMP(1);
-      part = product(q.reverse ? t - 1 : t + 1);
-      P_STAMP(3);
+      part = gather((T - 1 - i) & 1);
+      P_STAMP(2);
     }
     if (cellt) {
       float ox[4] = {0.f, 0.f, 0.f, 0.f}, oh[4] = {0.f, 0.f, 0.f, 0.f};
@@ -412,7 +422,10 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
         const float dh = dh_carry + dhs_t + part;
         dh_carry = cell_bwd_point<CELL>(live, dh, dc, gl, 1, hin, cin, cout, ox, CELL == CELL_GRU ? oh : nullptr);
       }
-      // 16-byte stores per (row, gate): gather the 4 units into the lane of unit 0
+      // A operand of the product: the h-side gradients
+#pragma unroll
+      for (int g = 0; g < G; ++g) dGl[crow][cu * G + g] = (CELL == CELL_GRU) ? oh[g] : ox[g];
+      // global copies for the weight gradients: 16-byte stores per (row, gate)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         f32x4v vx, vh;
@@ -424,13 +437,52 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
         }
         if (crv && cu == 0) {
           const long o = ((long)t * R + crow) * GH + g * H + u0;
-          if (CELL == CELL_GRU) {
-            *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
-            st16_sc1(rs_dgh, o, vh);                 // h-side gradients: the hand-off payload
-          } else {
-            st16_sc1(rs_dgh, o, vx);                 // LSTM: x side == h side (normally one buffer)
-            if (q.dgx != dgh_base) *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
+          *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
+          if (CELL == CELL_GRU) *reinterpret_cast<f32x4v*>(dgh_base + o) = vh;
+          else if (q.dgx != dgh_base) *reinterpret_cast<f32x4v*>(dgh_base + o) = vx;
+        }
+      }
+    }
+    __syncthreads();
+    P_STAMP(3);
+    // product: two 16-row fragments x this wave's column fragments, K = 16 (4 steps)
+    {
+      float a[2][4];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[f][s] = dGl[16 * f + l15][4 * s + kq];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nf = wave + 16 * j;
+        if (nf < nfr) {
+          f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], w[j][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], w[j][s], acc1, 0, 0, 0);
           }
+          // C layout: acc[r] = (row 16f + 4*kq + r, column 16*nf + l15)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            tile[(4 * kq + r) * LDT + 16 * nf + l15] = acc0[r];
+            tile[(16 + 4 * kq + r) * LDT + 16 * nf + l15] = acc1[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // publish, destination-major: piece (dest d, row r) = tile[r][4d .. 4d+3] -> ex[parity][d][me][r][0..3]
+    {
+      const long wbase = (long)((T - i) & 1) * ex_par + (long)blockIdx.x * 128;
+      const int npieces = nb * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pc = tid + P_THREADS * j;
+        if (pc < npieces) {
+          const int d = pc >> 5, r = pc & 31;
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + r * LDT + 4 * d);
+          st16_sc1(rs_ex, wbase + ((long)d * nb) * 128 + (long)r * 4, v);
         }
       }
     }
@@ -438,11 +490,11 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     publish(flg, (unsigned)(T - i));
     P_STAMP(5);
   }
-  // gradient wrt the initial state: carry + product with the first step's dG
+  // gradient wrt the initial state: carry + the last product
   float part = 0.f;
   if (T > 0) {
     if (!wait_flags(flg, nb, (unsigned)T, p.status, &s_abort)) return;
-    part = product(q.reverse ? T - 1 : 0);
+    part = gather(T & 1);
   }
   if (crv) {
     q.dh0[(long)crow * H + cn] = dh_carry + part;
@@ -524,9 +576,22 @@ bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns) {
   static int on = -1;
   if (on < 0) {
     const char* e = getenv("CVAE_PERSISTENT_RNN_BWD");
-    on = (e && e[0] == '1') ? 1 : 0;      // opt-in: the one-launch-per-step path is faster for now
+    on = (e && e[0] == '0') ? 0 : 1;
   }
   return on && rnn_persist_supported(cell, T, R, H, ns);
+}
+
+static float* g_exch = nullptr;
+static long g_exch_floats = 0;
+static int persist_exch(long floats, float** out) {
+  if (floats > g_exch_floats) {
+    if (g_exch) CVAE_TRY(check_hip(hipFree(g_exch), "persist exchange free"));     // implicit device sync
+    g_exch = nullptr; g_exch_floats = 0;
+    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_exch), (size_t)floats * sizeof(float)), "persist exchange"));
+    g_exch_floats = floats;
+  }
+  *out = g_exch;
+  return 0;
 }
 
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
@@ -537,17 +602,28 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
   p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
   const int G = a[0].cell == CELL_GRU ? 3 : 4;
-  const int GH = G * p.H;
-  CVAE_REQUIRE(GH % 128 == 0 && GH / 32 <= 64, "rnn_backward_persist: G*H=%d does not split over the block's waves", GH);
+  const int nb = p.H / P_HU;
+  CVAE_REQUIRE(p.H % 16 == 0 && p.H / 16 <= 32, "rnn_backward_persist: H=%d", p.H);
+  CVAE_TRY(persist_exch((long)ns * 2 * nb * nb * 128, &p.exch));
   for (int k = 0; k < ns; ++k) {
     const RnnBwd& r = a[k];
     float* dgh = r.dgh ? r.dgh : r.dgx;
-    CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0 &&
-                 (reinterpret_cast<uintptr_t>(r.W_hh) & 15) == 0, "rnn_backward_persist: operands must be 16-byte aligned");
+    CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0,
+                 "rnn_backward_persist: operands must be 16-byte aligned");
     p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse};
   }
-  const size_t lds = (size_t)(4 * (GH + 4) + 16 * 32 * 4) * sizeof(float);
-  const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
+  long lds_floats = 32L * (p.H + 4);
+  if (lds_floats < 4096) lds_floats = 4096;
+  const size_t lds = (size_t)lds_floats * sizeof(float);
+  const dim3 grid(nb, ns), block(P_THREADS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "persist bwd LDS attribute"));
+    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "persist bwd LDS attribute"));
+    attr_set = true;
+  }
   ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
   if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_GRU>, grid, block, lds, s, p);
   else hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_LSTM>, grid, block, lds, s, p);
@@ -566,7 +642,7 @@ int persist_status_and_clear() {
     unsigned long long acc[16];
     if (hipMemcpy(acc, persist_stamps(), sizeof(acc), hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "[cvae persist stamps, cycles of block (0,0)] loop-top->wait %llu | wait %llu | load+mfma %llu | reduce %llu | "
-              "cell+stores %llu | drain+flag %llu || bwd product: loads %llu | mfma %llu | shfl+sync %llu\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8]);
+              "cell+stores %llu | drain+flag %llu   (bwd: top | wait | gather | cell | product+publish stores | drain+flag)\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
       if (hipMemset(persist_stamps(), 0, sizeof(acc)) != hipSuccess) return -1;
     }
   }
