@@ -338,6 +338,57 @@ int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd
   return linear_nt(hs + 2 * RH, W_c, Hd, b_c, ACT_TANH, T * R, E, Hd, final, s);
 }
 
+// Importance-weighted evaluation layout: rows are sentence-major (r = b*K + k, K samples of each
+// of B sentences) and the caller has ordered the sentences by non-increasing target length, so
+// the rows still inside their sentence at step t are the prefix [0, live_sent[t]*K).  Each step's
+// recurrent product, cell update and W_c projection run on that prefix only; rows of hs/cs/final
+// past it are left untouched (their targets are <pad>, which cvae_projce_forward never reads).
+// Same arithmetic per live row as cvae_decoder_forward(train=0).  live_sent is a HOST array.
+int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, int64_t V, const float* init,
+                                const int64_t* go, const float* emb, const int* live_sent, const float* const* w,
+                                float* X, float* xproj, float* xadd, float* hp, float* hs, float* cs, float* final,
+                                void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_forward_sorted: bad cell");
+  CVAE_REQUIRE(B > 0 && K > 0 && T > 0 && E > 0 && Hd > 0 && V > 0 && (long)B * K <= INT_MAX,
+               "decoder_forward_sorted: bad shape B=%d K=%d T=%d E=%d Hd=%d", B, K, T, E, Hd);
+  const int R = B * K;
+  CVAE_REQUIRE(R > SKINNY_MAX_ROWS, "decoder_forward_sorted: needs B*K > %d rows (use cvae_decoder_forward)",
+               SKINNY_MAX_ROWS);
+  CVAE_REQUIRE(init && go && emb && live_sent && w && X && xproj && xadd && hp && hs && final,
+               "decoder_forward_sorted: null operand");
+  CVAE_REQUIRE(cell == CELL_GRU || cs, "decoder_forward_sorted: LSTM needs cs");
+  std::vector<int> live(T);
+  for (int t = 0; t < T; ++t) {
+    CVAE_REQUIRE(live_sent[t] >= 0 && live_sent[t] <= B && (t == 0 || live_sent[t] <= live_sent[t - 1]),
+                 "decoder_forward_sorted: live_sent must be non-increasing within [0,B] (t=%d: %d)", t, live_sent[t]);
+    live[t] = live_sent[t] * K;
+  }
+  const int G = gates_of(cell);
+  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* b_ih = w[2]; const float* b_hh = w[3];
+  const float* W_c = w[4]; const float* b_c = w[5];
+  const long RH = (long)R * Hd, GH = (long)G * Hd;
+  float* xinit = xadd;              // [R, G*Hd]
+  float* x0 = xadd + (long)R * GH;  // [R, G*Hd]
+  CVAE_TRY(launch_embed(T, B, E, 0, 0, go, B, emb, nullptr, nullptr, nullptr, X, s));
+  CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, T * B, (int)GH, E, xproj, s));
+  CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, R, (int)GH, E, xinit, s));
+  CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, R, (int)GH, E, x0, s));
+  RnnFwd f0 = {};
+  f0.cell = cell; f0.T = 1; f0.R = R; f0.H = Hd; f0.xproj = x0; f0.xmod = R; f0.xadd = xinit;
+  f0.W_hh = W_hh; f0.b_hh = b_hh; f0.hs = hs; f0.cs = cs; f0.hp_scratch = hp;
+  CVAE_TRY(launch_rnn_forward(f0, s));
+  RnnFwd f = f0;
+  f.T = T; f.xproj = xproj; f.xmod = B; f.xdiv = K; f.live_rows = live.data();
+  f.hs = hs + RH; f.cs = cs ? cs + RH : nullptr;
+  f.init_in_place = 1;
+  CVAE_TRY(launch_rnn_forward(f, s));
+  for (int t = 0; t < T; ++t)
+    if (live[t] > 0)
+      CVAE_TRY(linear_nt(hs + (t + 2) * RH, W_c, Hd, b_c, ACT_TANH, live[t], E, Hd, final + (long)t * R * E, s));
+  return 0;
+}
+
 int cvae_decoder_forward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const float* const* init,
                            const int64_t* go, const float* emb, const float* const* mask_in,
                            const float* const* mask_out, const float* const* w, float* const* X,
@@ -500,6 +551,12 @@ int cvae_projce_backward(const float* final, const float* W, const float* b, con
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream) {
   CVAE_REQUIRE(B > 0 && R % B == 0, "targets_time_major: R must be a multiple of B");
   return launch_targets_tm(eos, B, T, R, tgt_tm, S(stream));
+}
+
+// sentence-major variant: row r = b*K + k reads sentence b
+int cvae_targets_sentence_major(const int64_t* eos, int B, int T, int K, int64_t* tgt_tm, void* stream) {
+  CVAE_REQUIRE(B > 0 && K > 0 && eos && tgt_tm, "targets_sentence_major: bad arguments");
+  return launch_targets_sm(eos, B, T, K, tgt_tm, S(stream));
 }
 
 int cvae_logits(const float* final, const float* W, const float* b, int T, int B, int E, int64_t V, float* tmp,

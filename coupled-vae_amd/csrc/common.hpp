@@ -165,6 +165,9 @@ struct RnnFwd {
   float* hs; float* cs;             // [(T+1),R,H]; cs null for GRU
   float* gates;                     // [T,R,4H] or null (saved for backward)
   float* hp_scratch;                // [R,G*H]; required when R > SKINNY_MAX_ROWS
+  // Large-R path only (IW eval, sentence-major rows r = sentence*xdiv + sample):
+  int xdiv;                         // > 1: row r uses x-side row (r / xdiv) % xmod
+  const int* live_rows;             // host [T] or null: step t touches rows [0, live_rows[t]) only
 };
 int launch_rnn_forward(const RnnFwd& a, hipStream_t s);
 // ns independent sequences with the same cell / T / R / H, advanced in lock-step

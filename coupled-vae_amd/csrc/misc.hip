@@ -299,6 +299,18 @@ int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hip
   CVAE_LAUNCH_CHECK("targets_tm_kernel");
   return 0;
 }
+__global__ void targets_sm_kernel(int B, int T, int K, const int64_t* __restrict__ eos, int64_t* __restrict__ out) {
+  const long R = (long)B * K;
+  IDX1D((long)T * R);
+  const int r = (int)(idx % R), t = (int)(idx / R);
+  out[idx] = eos[(long)(r / K) * T + t];
+}
+int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s) {
+  if ((long)T * B * K == 0) return 0;
+  hipLaunchKernelGGL(targets_sm_kernel, GRID1D((long)T * B * K), 0, s, B, T, K, eos, out);
+  CVAE_LAUNCH_CHECK("targets_sm_kernel");
+  return 0;
+}
 
 // logits[b, t, v] = tmp[t*B + b, v]
 __global__ void logits_bt_kernel(int T, int B, long V, const float* __restrict__ tmp, float* __restrict__ out) {

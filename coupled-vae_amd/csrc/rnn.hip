@@ -18,7 +18,7 @@ namespace cvae {
 // ------------------------------------------------------------------ forward cell (large R)
 template <int CELL>
 __global__ __launch_bounds__(256) void cell_fwd_kernel(
-    int R, int H, const float* __restrict__ hp, const float* __restrict__ xproj, int xmod,
+    int R, int H, const float* __restrict__ hp, const float* __restrict__ xproj, int xmod, int xdiv,
     const float* __restrict__ xadd, const float* __restrict__ b_hh,
     const float* __restrict__ h_prev, const float* __restrict__ c_prev,
     float* __restrict__ h_out, float* __restrict__ c_out, float* __restrict__ gates,
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(
   const int r = (int)(idx / H), n = (int)(idx % H);
   const bool live = (lengths == nullptr) || ((int64_t)t < lengths[r]);
   const float* hpr = hp + (long)r * G * H + n;
-  const float* xp = xproj + (long)(r % xmod) * G * H + n;
+  const float* xp = xproj + (long)((r / xdiv) % xmod) * G * H + n;
   const float* xa = xadd ? xadd + (long)r * G * H + n : nullptr;
   float x[G], s[G];
 #pragma unroll
@@ -69,6 +69,9 @@ static int rnn_forward_check(const RnnFwd& a) {
   CVAE_REQUIRE(a.xproj && a.W_hh && a.b_hh && a.hs, "rnn_forward: null operand");
   CVAE_REQUIRE(a.cell == CELL_GRU || a.cs, "rnn_forward: LSTM needs cs");
   CVAE_REQUIRE(a.R % a.xmod == 0, "rnn_forward: R must be a multiple of xmod");
+  CVAE_REQUIRE((a.xdiv <= 1 && !a.live_rows) || a.R > SKINNY_MAX_ROWS,
+               "rnn_forward: xdiv / live_rows need R > %d", SKINNY_MAX_ROWS);
+  CVAE_REQUIRE(a.xdiv <= 1 || a.R % ((long)a.xdiv * a.xmod) == 0, "rnn_forward: R must be a multiple of xdiv*xmod");
   CVAE_REQUIRE(a.R <= SKINNY_MAX_ROWS || a.hp_scratch, "rnn_forward: hp_scratch required for R > %d", SKINNY_MAX_ROWS);
   return 0;
 }
@@ -105,23 +108,27 @@ static void rnn_forward_step_args(const RnnFwd& a, int i, SkinnyArgs& k) {
 
 static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
   const int G = a.cell == CELL_GRU ? 3 : 4;
-  const long RH = (long)a.R * a.H;
+  const int xdiv = a.xdiv > 1 ? a.xdiv : 1;
   for (int i = 0; i < a.T; ++i) {
     SkinnyArgs k;
     rnn_forward_step_args(a, i, k);
+    const int live = a.live_rows ? a.live_rows[k.t] : a.R;
+    CVAE_REQUIRE(live >= 0 && live <= a.R, "rnn_forward: live_rows[%d]=%d outside [0,%d]", k.t, live, a.R);
+    if (live == 0) continue;
+    const long RH = (long)live * a.H;
     GemmDesc d = {};
-    d.transA = 0; d.transB = 1; d.M = a.R; d.N = G * a.H; d.K = a.H;
+    d.transA = 0; d.transB = 1; d.M = live; d.N = G * a.H; d.K = a.H;
     d.A = k.A; d.lda = a.H; d.B = a.W_hh; d.ldb = a.H; d.C = a.hp_scratch; d.ldc = (long)G * a.H;
     CVAE_TRY(launch_gemm(d, s));
     const int grid = cdiv(RH, 256);
     // algorithmic bytes: hp + x-side (G each) + h_prev in, h out (+ c in/out for LSTM)
     ProfScope prof(PK_CELL_FWD, s, 4.0 * RH * (2 * G + 2 + (a.cell == CELL_LSTM ? 2 : 0)));
     if (a.cell == CELL_GRU)
-      hipLaunchKernelGGL((cell_fwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, k.xproj,
-                         a.xmod, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
+      hipLaunchKernelGGL((cell_fwd_kernel<CELL_GRU>), dim3(grid), dim3(256), 0, s, live, a.H, a.hp_scratch, k.xproj,
+                         a.xmod, xdiv, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
     else
-      hipLaunchKernelGGL((cell_fwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, a.R, a.H, a.hp_scratch, k.xproj,
-                         a.xmod, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
+      hipLaunchKernelGGL((cell_fwd_kernel<CELL_LSTM>), dim3(grid), dim3(256), 0, s, live, a.H, a.hp_scratch, k.xproj,
+                         a.xmod, xdiv, a.xadd, a.b_hh, k.h_prev, k.c_prev, k.h_out, k.c_out, k.gates, a.lengths, k.t);
     CVAE_LAUNCH_CHECK("cell_fwd_kernel");
   }
   return 0;

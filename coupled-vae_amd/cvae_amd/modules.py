@@ -190,6 +190,12 @@ class Decoder(nn.Module):
         cell = ops.LSTM if self.use_lstm else ops.GRU
         return ops.decoder(cell, train, init_input, helper, mask_in, mask_out, self.Embedding.weight, w)
 
+    def final_states_sorted(self, init_input, helper, live_sent):
+        rnn = self.LSTM if self.use_lstm else self.GRU
+        w = _rnn_weights(rnn) + [self.W_c.weight, self.W_c.bias]
+        cell = ops.LSTM if self.use_lstm else ops.GRU
+        return ops.decoder_sorted(cell, init_input, helper, live_sent, self.Embedding.weight, w)
+
     def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None):
         if not (self.training or test_lm):
             raise NotImplementedError('greedy / beam decoding is outside the accelerated hot path (SURVEY 8f.3)')
@@ -260,16 +266,46 @@ def _iw_nll(decoder, to_init_seq, go, eos, mu, sigma, mu_p, sigma_p, post_repr, 
     z = ops.rsample_n(mu, sigma, eps)                                   # (K,B,Z)
     kc = max(1, min(n_sample, settings.iw_max_rows // B))
     xent = torch.empty((n_sample, B), dtype=torch.float32, device=dev)
+    plan = _sorted_plan(eos, pad) if settings.sort_eval and kc * B > ops.SKINNY_MAX_ROWS else None
+    W, bias = decoder.ToVocab.weight, decoder.ToVocab.bias
     for k0 in range(0, n_sample, kc):
         k1 = min(n_sample, k0 + kc)
-        zz = z[k0:k1].reshape(-1, Z)
-        init = to_init(to_init_seq, zz)
-        if post_repr is not None:
-            init = init + post_repr.repeat(k1 - k0, 1)
-        final = decoder.final_states(init, go, False)
-        xent[k0:k1] = ops.proj_ce(final, decoder.ToVocab.weight, decoder.ToVocab.bias, eos, pad).view(k1 - k0, B)
+        if plan is not None and (k1 - k0) * B > ops.SKINNY_MAX_ROWS:
+            order, live_sent = plan
+            zz = z[k0:k1].index_select(1, order).transpose(0, 1).reshape(-1, Z)      # row b*(k1-k0) + k
+            init = to_init(to_init_seq, zz)
+            if post_repr is not None:
+                init = init + post_repr.index_select(0, order).repeat_interleave(k1 - k0, 0)
+            go_s, eos_s = go.index_select(0, order), eos.index_select(0, order)
+            final = decoder.final_states_sorted(init, go_s, live_sent)
+            xs = ops.proj_ce_sorted(final, W, bias, eos_s, pad).view(B, k1 - k0)
+            xent[k0:k1].index_copy_(1, order, xs.t())
+        else:
+            zz = z[k0:k1].reshape(-1, Z)
+            init = to_init(to_init_seq, zz)
+            if post_repr is not None:
+                init = init + post_repr.repeat(k1 - k0, 1)
+            final = decoder.final_states(init, go, False)
+            xent[k0:k1] = ops.proj_ce(final, W, bias, eos, pad).view(k1 - k0, B)
     xm, nll, kl = ops.iw_reduce(z, xent, mu, sigma, mu_p, sigma_p)
     return xm, nll, kl, z.transpose(0, 1)
+
+
+def _sorted_plan(eos, pad):
+    """Order sentences by non-increasing target length so that the rows still decoding at step t
+    are a prefix (ops.decoder_sorted).  One device->host copy of B lengths per batch.  Returns
+    None when some sentence has <pad> inside its target (then no prefix exists)."""
+    B, T = eos.shape
+    live = eos != pad
+    lens = live.sum(1)
+    steps = torch.arange(T, device=eos.device)
+    prefix_ok = (live == (steps[None, :] < lens[:, None])).all()
+    host = torch.cat([lens, prefix_ok.view(1).to(lens.dtype)]).cpu()
+    if int(host[-1]) == 0:
+        return None
+    order = torch.argsort(lens, descending=True, stable=True)
+    live_sent = (host[:-1][None, :] > torch.arange(T)[:, None]).sum(1).to(torch.int32).contiguous()
+    return order, live_sent
 
 
 def _truncate_eval(go, eos, bare, sent_len):

@@ -9,6 +9,7 @@ from . import _lib
 from ._lib import call, ptr, ptr_array, query, stream
 
 GRU, LSTM = 0, 1
+SKINNY_MAX_ROWS = 256      # csrc/common.hpp: above this row count the recurrence runs as tiled GEMM + cell kernel
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_EXP = 0, 1, 2, 3
 
 
@@ -206,6 +207,34 @@ def decoder(cell, train, init, go, mask_in, mask_out, emb, w):
     return DecoderFn.apply(cell, True, init, go, mask_in, mask_out, emb, *w)
 
 
+def decoder_sorted(cell, init, go, live_sent, emb, w):
+    """IW-eval decoder on sentence-major rows (cvae_decoder_forward_sorted): init (B*K,E) with row
+    b*K+k = sample k of sentence b, go (B,T) ordered by non-increasing length, live_sent = host
+    int32 (T,) count of sentences still inside their target at step t.  -> final (T,B*K,E) whose
+    rows past live_sent[t]*K are zero-filled and never computed."""
+    with torch.no_grad():
+        init, go, emb = _c(init), _c(go), _c(emb)
+        w = [_c(t) for t in w]
+        R, E = init.shape
+        B, T = go.shape
+        K = R // B
+        assert R == B * K and live_sent.dtype == torch.int32 and live_sent.device.type == 'cpu' and \
+            live_sent.numel() == T and live_sent.is_contiguous()
+        V = emb.shape[0]
+        Hd = w[1].shape[1]
+        G = gates_of(cell)
+        hs = _f((T + 2, R, Hd), emb)
+        cs = _f((T + 2, R, Hd), emb) if cell == LSTM else None
+        final = torch.zeros((T, R, E), dtype=torch.float32, device=emb.device)
+        hp = _f((R, G * Hd), emb)
+        X, xproj, xadd = _f((T, B, E), emb), _f((T, B, G * Hd), emb), _f((2, R, G * Hd), emb)
+        warr = ptr_array(w)
+        call('cvae_decoder_forward_sorted', cell, B, K, T, E, Hd, V, ptr(init), ptr(go), ptr(emb),
+             live_sent.data_ptr(), warr, ptr(X), ptr(xproj), ptr(xadd), ptr(hp), ptr(hs), ptr(cs), ptr(final),
+             stream())
+        return final
+
+
 class DecoderPairFn(torch.autograd.Function):
     """Two training decoders of identical shape (Decoder / DecoderCouple) advanced in lock-step:
     every timestep of both recurrences is one launch (cvae_decoder_forward_n).
@@ -285,6 +314,14 @@ def targets_time_major(eos, R):
     return out
 
 
+def targets_sentence_major(eos, K):
+    eos = _c(eos)
+    B, T = eos.shape
+    out = torch.empty((T * B * K,), dtype=torch.int64, device=eos.device)
+    call('cvae_targets_sentence_major', ptr(eos), B, T, K, ptr(out), stream())
+    return out
+
+
 class ProjCEFn(torch.autograd.Function):
     """ToVocab + SeqLoss(keep_batch=True): per-sentence summed CE (R,), logits never stored."""
 
@@ -318,6 +355,13 @@ class ProjCEFn(torch.autograd.Function):
 def proj_ce(final, W, b, eos, pad):
     """final (T,R,E), eos (B,T) with R % B == 0 -> (R,)."""
     tgt = targets_time_major(eos, final.shape[1])
+    return ProjCEFn.apply(final, W, b, tgt, pad)
+
+
+def proj_ce_sorted(final, W, b, eos, pad):
+    """final (T,B*K,E) on sentence-major rows, eos (B,T) -> (B*K,)."""
+    B = eos.shape[0]
+    tgt = targets_sentence_major(eos, final.shape[1] // B)
     return ProjCEFn.apply(final, W, b, tgt, pad)
 
 

@@ -89,6 +89,19 @@ int cvae_decoder_forward(int cell, int train, int B, int R, int T, int E, int Hd
                          const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
                          const float* const* w, float* X, float* xproj, float* xadd, float* hp, float* hs,
                          float* cs, float* gates, float* hdrop, float* final, void* stream);
+/* IW-eval variant of the train == 0 branch for the importance-sampling loop
+ * (Modules/vae_couple.py:526-578): rows are sentence-major, r = b*K + k for sample k of
+ * sentence b, and the caller has ordered the B sentences by non-increasing target length, so
+ * the rows with a non-<pad> target at step t are the prefix [0, live_sent[t]*K).  Each step
+ * computes that prefix only; rows of hs/cs/final past it are left untouched (their targets are
+ * <pad> and cvae_projce_forward never reads them).  Per live row the arithmetic is that of
+ * cvae_decoder_forward(train=0).  live_sent: HOST int[T], non-increasing, within [0,B].
+ * Requires B*K > 256 (smaller row counts take cvae_decoder_forward).  Buffers as in the
+ * train == 0 branch with R = B*K; hp is required. */
+int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, int64_t V, const float* init,
+                                const int64_t* go, const float* emb, const int* live_sent, const float* const* w,
+                                float* X, float* xproj, float* xadd, float* hp, float* hs, float* cs, float* final,
+                                void* stream);
 int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd);
 /* dfinal[T,B,E] -> dinit[B,E] (overwritten), dw[6] (overwritten), demb[V,E] (ACCUMULATED). */
 int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
@@ -134,6 +147,8 @@ int cvae_projce_backward(const float* final, const float* W, const float* b, con
                          float* dfinal, float* dW, float* db, float* ws, void* stream);
 /* tgt_tm[t*R + r] = eos[(r % B)*T + t]: time-major targets for R = n*B rows. */
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream);
+/* tgt_tm[t*B*K + r] = eos[(r / K)*T + t]: the same for sentence-major rows r = b*K + k. */
+int cvae_targets_sentence_major(const int64_t* eos, int B, int T, int K, int64_t* tgt_tm, void* stream);
 /* Materialise logits[B,T,V] (batch-major, as the reference returns them) for callers that
  * index them; not used on the hot path. */
 int cvae_logits(const float* final, const float* W, const float* b, int T, int B, int E, int64_t V, float* tmp,

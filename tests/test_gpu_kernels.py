@@ -207,6 +207,41 @@ def test_decoder_forward_backward(dev, cell, shape):
         assert rel(got_e, ref_e) < 2e-5, n_rep
 
 
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+@pytest.mark.parametrize('shape', [(6, 9, 16, 32, 40, 50), (12, 21, 40, 128, 90, 30)])
+def test_decoder_forward_sorted(dev, cell, shape):
+    """cvae_decoder_forward_sorted (sentence-major rows, finished rows skipped) against the plain
+    eval branch on the same rows: live rows equal, skipped rows untouched (zero)."""
+    from cvae_amd import ops
+    B, T, E, Hd, V, K = shape
+    g = torch.Generator().manual_seed(8)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    lens = torch.sort(lens, descending=True).values
+    go = torch.randint(1, V, (B, T), generator=g)
+    emb = torch.randn(V, E, generator=g)
+    ws = _rnn_params(cell, 2 * E, Hd, False, 4)
+    k = 1.0 / math.sqrt(Hd)
+    W_c, b_c = (torch.rand(E, Hd, generator=g) * 2 - 1) * k, (torch.rand(E, generator=g) * 2 - 1) * k
+    init = torch.randn(K, B, E, generator=g)                               # sample-major (k, b)
+    c = ops.GRU if cell == 'gru' else ops.LSTM
+    w_d = [w.to(dev) for w in ws + [W_c, b_c]]
+    plain = ops.decoder(c, False, init.reshape(K * B, E).to(dev), go.to(dev), None, None, emb.to(dev), w_d)
+    plain = plain.view(T, K, B, E).transpose(1, 2)                         # (T, B, K, E)
+    live_sent = (lens[None, :] > torch.arange(T)[:, None]).sum(1).to(torch.int32)
+    init_s = init.transpose(0, 1).reshape(B * K, E).to(dev)               # row b*K + k
+    got = ops.decoder_sorted(c, init_s, go.to(dev), live_sent, emb.to(dev), w_d).view(T, B, K, E)
+    for t in range(T):
+        n = int(live_sent[t])
+        # small live prefixes take another GEMM kernel (different summation order): fp32 tolerance
+        assert (got[t, :n] - plain[t, :n]).abs().max().item() < 2e-5, t
+        assert not got[t, n:].any(), t
+    # sentence-major targets
+    eos = torch.where(torch.arange(T)[None, :] < lens[:, None], go, torch.zeros_like(go)).to(dev)
+    tgt = ops.targets_sentence_major(eos, K).view(T, B, K)
+    assert torch.equal(tgt, eos.t()[:, :, None].expand(T, B, K))
+
+
 # E = 16/32/200: exact-K register path; 30/104: zero-padded K; 208: generic fallback (E > 200);
 # V off the 32-column tile; R*T above and below one 128-row item
 @pytest.mark.parametrize('shape', [(7, 5, 16, 50), (40, 32, 200, 10002), (3, 700, 200, 20001), (6, 9, 30, 77),

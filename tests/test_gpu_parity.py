@@ -286,14 +286,17 @@ def test_iw_nll_vs_oracle_and_row_chunking(dev, cell):
     tr.model.train(False)
     outs = []
     try:
-        for rows in (16384, 5 * B):
-            settings.iw_max_rows = rows
+        # 320 rows in one pass: sentence-major length-sorted layout; 80 rows: plain layout (skinny
+        # recurrence); 17 samples a pass: sorted passes + a plain tail; last: sorted layout off
+        for rows, srt in ((16384, True), (5 * B, True), (17 * B, True), (16384, False)):
+            settings.iw_max_rows, settings.sort_eval = rows, srt
             modules.set_noise_source(modules.ReplayNoise({'iw_eps': _chunks(eps)}))
             outs.append(tr.model.test_lm(bare=batch['bare'], sent_len=batch['len'], go=batch['go'], eos=batch['eos'],
                                          n_sample=K))
     finally:
-        settings.iw_max_rows = 16384
+        settings.iw_max_rows, settings.sort_eval = 16384, True
         modules.set_noise_source(None)
     assert rel(outs[0][0], xent) < LOSS_TOL and rel(outs[0][1], nll) < LOSS_TOL and rel(outs[0][2], kl) < 5e-4
-    for a, b in zip(outs[0][:3], outs[1][:3]):
-        assert rel(a, b) < 1e-6
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:3], other[:3]):
+            assert rel(a, b) < 1e-6
