@@ -48,6 +48,18 @@ __device__ __forceinline__ float4 ld4g(const float* __restrict__ src, int k, int
   return r;
 }
 
+// blocks of one gemm_wide launch: CVAE_WIDE_BLOCKS_PER_CU (default 2) per CU
+static int wide_grid_blocks() {
+  static int nblk = 0;
+  if (!nblk) {
+    const char* e = getenv("CVAE_WIDE_BLOCKS_PER_CU");
+    int per = e ? atoi(e) : 2;
+    if (per < 1 || per > 3) per = 2;
+    nblk = persistent_grid_blocks() / 2 * per;
+  }
+  return nblk;
+}
+
 // Work layout, computed identically by the GEMM blocks and by the reduction kernel.
 struct WideLayout { int Mlim, Klim, mt, ks, kchunk; };
 __device__ __forceinline__ WideLayout wide_layout(const G224Args& p, int nblk) {
@@ -107,7 +119,46 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
     const int kbeg = ksp * kchunk, kend = min(Klim, kbeg + kchunk);
 
     float4 sa[2], sb[4];
-    auto stage_load = [&](int k0) {
+    // Interior chunks (every load a whole in-bounds float4) take a branch-free path on
+    // pointers set up once per item; edge tiles and the K tail take the guarded path.
+    // Rows of A past Mlim are clamped to a valid row: their accumulators are never stored.
+    const bool fast_item = p.vecA && p.vecB && ncols == tw && (AKC || m0 + G2_BM <= Mlim);
+    const float* pa[2];
+    const float* pb[4];
+    int brn[4];                                // dev_bound == 2: B row index of the next interior chunk
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      if (AKC) pa[i] = p.A + (long)min(m0 + (idx >> 2), Mlim - 1) * p.lda + kbeg + 4 * (idx & 3);
+      else pa[i] = p.A + (long)(kbeg + (idx >> 5)) * p.lda + m0 + 4 * (idx & 31);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = max(bkr[i], 0);
+      pb[i] = p.B + ((p.dev_bound == 2) ? 0L : (long)(kbeg + kr) * p.ldb) + n0 + bc[i];
+      brn[i] = (p.dev_bound == 2) ? p.rows[p.r0 + min(kbeg + kr, Klim - 1)] : 0;
+    }
+    const long a_step = AKC ? (long)G2_BK : (long)G2_BK * p.lda;
+    const long b_step = (long)G2_BK * p.ldb;
+    int knext = kbeg + G2_BK;                  // first k of the chunk after the one being loaded
+    // loads the next interior chunk of this item (chunks are taken in order)
+    auto fast_load = [&]() {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { sa[i] = *reinterpret_cast<const float4*>(pa[i]); pa[i] += a_step; }
+      if (p.dev_bound == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (bkr[i] >= 0) sb[i] = *reinterpret_cast<const float4*>(pb[i] + (long)brn[i] * p.ldb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) brn[i] = p.rows[p.r0 + min(knext + max(bkr[i], 0), Klim - 1)];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (bkr[i] >= 0) { sb[i] = *reinterpret_cast<const float4*>(pb[i]); pb[i] += b_step; }
+      }
+      knext += G2_BK;
+    };
+    auto edge_load = [&](int k0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = tid + 256 * i;
@@ -150,13 +201,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    stage_load(kbeg);
-    stage_store(0);
-    __syncthreads();
     const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) stage_load(kbeg + (kt + 1) * G2_BK);
+    const int nfast = fast_item ? (kend - kbeg) / G2_BK : 0;   // interior chunks form a prefix
+    auto compute = [&](int buf) {
       // the chunk's 8 MFMA steps: (q, s) uses k = 8q + 4*lhi + s
       float a[8];
       if (AKC) {
@@ -197,7 +244,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
           acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b2[cur], acc[6], 0, 0, 0);
         }
       }
-      if (kt + 1 < nk) stage_store(buf ^ 1);
+    };
+    if (nfast > 0) fast_load(); else edge_load(kbeg);
+    stage_store(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nfast; ++kt) {             // steady state: the next chunk is interior too
+      fast_load();
+      compute(kt & 1);
+      stage_store((kt & 1) ^ 1);
+      __syncthreads();
+    }
+    for (; kt < nk; ++kt) {                    // K tail / edge tiles
+      if (kt + 1 < nk) edge_load(kbeg + (kt + 1) * G2_BK);
+      compute(kt & 1);
+      if (kt + 1 < nk) stage_store((kt & 1) ^ 1);
       __syncthreads();
     }
 
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_wide_reduce_kernel(G224Args p, int n
 // Partial-sum slabs: at most persistent_grid_blocks() tiles of 128 rows are in flight per launch.
 long gemm_wide_part_floats(int N, bool extra) {
   const long ld = (N + (extra ? 1 : 0) + 3) / 4 * 4;
-  return (long)persistent_grid_blocks() * G2_BM * ld;
+  return (long)wide_grid_blocks() * G2_BM * ld;
 }
 
 // Library-owned scratch for callers that bring none (one buffer per process, grown on demand;
@@ -308,7 +369,7 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
   a.part_ld = (n_eff + 3) / 4 * 4;
   if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part));
-  const int nblk = persistent_grid_blocks();
+  const int nblk = wide_grid_blocks();
   const dim3 grid(nblk), block(256);
   {
     double pm = a.M, pk = a.K;
