@@ -36,7 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
            3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
-           6: ('rnn_persist_kernel', 'mfma')}
+           6: ('rnn_fwd_persist_kernel', 'mfma'), 7: ('rnn_bwd_persist_kernel', 'mfma')}
 
 
 def parse():
@@ -93,7 +93,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def roofline_of(prof):
+def roofline_of(prof, region):
     """The kernel with the largest total time in the profiled pass."""
     name, rec = max(prof.items(), key=lambda kv: kv[1]['ms'])
     if rec['launches'] == 0 or rec['ms'] == 0:
@@ -103,7 +103,7 @@ def roofline_of(prof):
         ach, peak, unit = per_s / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
     else:
         ach, peak, unit = per_s / 1e9, PEAK_HBM_GBS, 'GB/s'
-    return dict(kernel=name, bound=rec['bound'], achieved=round(ach, 3), peak=peak, unit=unit,
+    return dict(kernel=name, region=region, bound=rec['bound'], achieved=round(ach, 3), peak=peak, unit=unit,
                 frac=round(ach / peak, 4), traffic=pmc_traffic(name), launches=rec['launches'],
                 avg_launch_ms=round(rec['ms'] / rec['launches'], 5),
                 work_per_launch=rec['work'] / rec['launches'])
@@ -217,21 +217,37 @@ def main():
         iw = dict(value=round(metrics['n'] / dt_iw, 3), unit='sentences/s', n_sample=args.iw_samples,
                   sentences=metrics['n'], seconds=round(dt_iw, 4))
 
-    # ---- roofline leg: same work once more with the library's per-kernel HIP events on
-    roof = None
+    # ---- roofline legs: the same work once more with the library's per-kernel HIP events on (events
+    # are recorded on the launch stream inside the library: cvae_profile_enable / cvae_profile_read).
+    # `roofline` = the kernel with the largest total time over the whole job, which is ce_core_kernel in
+    # the IW-NLL evaluation; `roofline_train` = the dominant kernel of the training step alone.
+    roof = roof_train = None
+    roof_all = {}
     if rank == 0:
+        def table(prof):
+            return {k: dict(launches=v['launches'], ms=round(v['ms'], 3),
+                            rate=round(v['work'] / max(v['ms'], 1e-9) / (1e9 if v['bound'] == 'mfma' else 1e6), 2),
+                            unit='TFLOP/s' if v['bound'] == 'mfma' else 'GB/s') for k, v in prof.items()}
         _lib.call('cvae_profile_enable', 1)
         for i in range(min(3, n_batches)):
             tr.train_step(batches[i])
-        if not args.no_iw:
-            tr.iw_eval(ebatches[1:2], args.iw_samples)
         torch.cuda.synchronize()
-        prof = profile_read(_lib.lib)
+        prof_t = profile_read(_lib.lib)
         _lib.call('cvae_profile_enable', 0)
-        roof = roofline_of(prof)
-        roof_all = {k: dict(launches=v['launches'], ms=round(v['ms'], 3),
-                            rate=round(v['work'] / max(v['ms'], 1e-9) / (1e9 if v['bound'] == 'mfma' else 1e6), 2),
-                            unit='TFLOP/s' if v['bound'] == 'mfma' else 'GB/s') for k, v in prof.items()}
+        roof_train = roofline_of(prof_t, 'train step (3 steps)')
+        roof_all['train'] = table(prof_t)
+        roof = roof_train
+        if not args.no_iw:
+            _lib.call('cvae_profile_enable', 1)
+            tr.iw_eval(ebatches[1:], args.iw_samples)
+            torch.cuda.synchronize()
+            prof_e = profile_read(_lib.lib)
+            _lib.call('cvae_profile_enable', 0)
+            roof_eval = roofline_of(prof_e, 'IW-NLL evaluation (%d batches)' % args.iw_batches)
+            roof_all['iw_nll'] = table(prof_e)
+            t_train = sum(v['ms'] for v in prof_t.values()) / 3.0 * (args.steps + args.warmup)
+            t_eval = sum(v['ms'] for v in prof_e.values()) * (args.iw_batches + 1.0) / args.iw_batches
+            roof = roof_eval if (roof_eval and t_eval >= t_train) else roof_train
     barrier_sync(world)
 
     if rank == 0:
@@ -245,7 +261,7 @@ def main():
                                    % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
                                       shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
                        'parallelism': 'dp%d' % world},
-            'iw_nll': iw, 'roofline': roof, 'kernels': roof_all,
+            'iw_nll': iw, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, shape)

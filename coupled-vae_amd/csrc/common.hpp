@@ -34,7 +34,7 @@ int check_hip(hipError_t e, const char* what);
 // ---- opt-in per-kernel timing (bench.py's roofline leg): HIP events recorded on the launch
 // stream around the kernels named below.  Off by default: no events, no overhead.
 enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_GEMM_WIDE = 5,
-                  PK_RNN_PERSIST = 6, PK_COUNT = 7 };
+                  PK_RNN_PERSIST = 6, PK_RNN_PERSIST_BWD = 7, PK_COUNT = 8 };
 struct ProfScope {
   int slot;
   hipStream_t s;

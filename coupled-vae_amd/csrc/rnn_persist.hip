@@ -624,7 +624,7 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "persist bwd LDS attribute"));
     attr_set = true;
   }
-  ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
+  ProfScope prof(PK_RNN_PERSIST_BWD, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
   if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_GRU>, grid, block, lds, s, p);
   else hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_LSTM>, grid, block, lds, s, p);
   CVAE_LAUNCH_CHECK("rnn_bwd_persist_kernel");

@@ -205,7 +205,9 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
  * own kernels on the launch stream (bench.py's roofline leg).  enable(1) resets and starts
  * recording (creates events on first use), enable(0) stops.  kernel: 0 tiled MFMA GEMM,
  * 1 skinny MFMA product / fused RNN step, 2 RNN cell forward, 3 RNN cell backward,
- * 4 projection+CE forward.  total_work: algorithmic FLOPs (0,1,4) or bytes (2,3). */
+ * 4 projection+CE core (forward and gradient), 5 long-K split GEMM (gemm_wide), 6 / 7 whole-sequence
+ * recurrent kernel forward / backward.  total_work: algorithmic FLOPs (0,1,4,5,6,7) or bytes (2,3);
+ * kernels whose row count lives on the device (4, 5) count the live rows. */
 int cvae_profile_enable(int on);
 int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_work);
 
