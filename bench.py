@@ -50,7 +50,17 @@ def parse():
     ap.add_argument('--iw-batches', type=int, default=2, help='evaluation batches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-iw', action='store_true')
+    ap.add_argument('--iw-shard', default='sentences', choices=['sentences', 'samples'],
+                    help='N > 1: shard evaluation batches over ranks (weak scaling, default) or the K samples of '
+                         'every sentence (same batches on every rank, all-gather of the cross-entropy rows)')
     return ap.parse_args()
+
+
+def log(rank, msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    if rank == 0 or os.environ.get('CVAE_BENCH_VERBOSE') == '1':
+        sys.stderr.write('[bench rank %d %s] %s\n' % (rank, time.strftime('%H:%M:%S'), msg))
+        sys.stderr.flush()
 
 
 def barrier_sync(world):
@@ -63,7 +73,7 @@ def barrier_sync(world):
 def max_over_ranks(x, world, dev):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() != 'gloo' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -166,17 +176,30 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    # CVAE_BENCH_REHEARSE=1: every rank on GPU 0 with gloo, to rehearse the N > 1 control flow on a
+    # one-GPU box (run it with CVAE_PERSISTENT_RNN=0: the whole-sequence kernels of two processes
+    # cannot be co-resident on one GPU).  Not a measurement.
+    rehearse = os.environ.get('CVAE_BENCH_REHEARSE') == '1'
+    if os.environ.get('CVAE_BENCH_WATCHDOG'):          # dump every thread's stack and exit if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['CVAE_BENCH_WATCHDOG']), exit=True)
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
-    from cvae_amd import _lib, data, harness
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
+    from cvae_amd import _lib, data, harness, settings
     _lib.init(local_rank)
 
     shape = data.SHAPES[args.workload]
     hp = harness.HParams(model='vae-couple', cell=args.cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'],
                          annealing_start=1000 if args.workload != 'ptb' else 2000,
                          euclidean_dist=(args.workload == 'yahoo'))
+    log(rank, 'world %d, device %s: building the model' % (world, dev))
     tr = harness.Trainer(hp, dev, seed=0)          # same seed: identical initial weights on every rank
     tr.iter_num = 20000                            # mid-annealing: lambda_KL > 0, every loss term live
     B = hp.batch_size
@@ -188,9 +211,11 @@ def main():
     tokens = [corpus.n_tokens(range(i * B, (i + 1) * B)) for i in range(n_batches)]
     torch.manual_seed(1234 + rank)                 # dropout / eps streams differ per rank
 
+    log(rank, 'training: %d warm-up + %d timed steps' % (args.warmup, args.steps))
     for i in range(args.warmup):
         tr.train_step(batches[i])
     barrier_sync(world)
+    log(rank, 'warm-up done')
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         tr.train_step(batches[i])
@@ -198,16 +223,22 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     tok = torch.tensor([float(sum(tokens[args.warmup:args.warmup + args.steps]))], dtype=torch.float64, device=dev)
     if world > 1:
+        if dist.get_backend() == 'gloo':
+            tok = tok.cpu()
         dist.all_reduce(tok)
     train_tok_s = float(tok.item()) / dt
+    log(rank, 'training done: %.3f ms/step' % (dt / max(args.steps, 1) * 1e3))
 
     # ---- IW-NLL evaluation (test.py path): sentences sharded over ranks
     iw = None
     if not args.no_iw:
+        by_samples = args.iw_shard == 'samples' and world > 1
+        settings.shard_samples = by_samples
         ev = data.Corpus(data.synthetic_sentences(B * (args.iw_batches + 1), shape['V'], shape['mu'], shape['sigma'],
-                                                  shape['cap'], seed=5000 + rank))
+                                                  shape['cap'], seed=5000 + (0 if by_samples else rank)))
         ebatches = [harness.text_batch(ev, range(i * B, (i + 1) * B), dev, truncate=False)
                     for i in range(args.iw_batches + 1)]
+        log(rank, 'IW-NLL: K=%d, %d batches (+1 warm-up), shard=%s' % (args.iw_samples, args.iw_batches, args.iw_shard))
         tr.iw_eval(ebatches[:1], args.iw_samples)                       # warm-up
         barrier_sync(world)
         t0 = time.perf_counter()
@@ -215,34 +246,40 @@ def main():
         barrier_sync(world)
         dt_iw = max_over_ranks(time.perf_counter() - t0, world, dev)
         iw = dict(value=round(metrics['n'] / dt_iw, 3), unit='sentences/s', n_sample=args.iw_samples,
+                  shard=args.iw_shard if world > 1 else 'none',
                   sentences=metrics['n'], seconds=round(dt_iw, 4))
 
     # ---- roofline legs: the same work once more with the library's per-kernel HIP events on (events
     # are recorded on the launch stream inside the library: cvae_profile_enable / cvae_profile_read).
     # `roofline` = the kernel with the largest total time over the whole job, which is ce_core_kernel in
     # the IW-NLL evaluation; `roofline_train` = the dominant kernel of the training step alone.
+    # Every rank runs the legs (their collectives must match); rank 0 records and reads the events.
     roof = roof_train = None
     roof_all = {}
-    if rank == 0:
-        def table(prof):
-            return {k: dict(launches=v['launches'], ms=round(v['ms'], 3),
-                            rate=round(v['work'] / max(v['ms'], 1e-9) / (1e9 if v['bound'] == 'mfma' else 1e6), 2),
-                            unit='TFLOP/s' if v['bound'] == 'mfma' else 'GB/s') for k, v in prof.items()}
-        _lib.call('cvae_profile_enable', 1)
-        for i in range(min(3, n_batches)):
-            tr.train_step(batches[i])
+
+    def table(prof):
+        return {k: dict(launches=v['launches'], ms=round(v['ms'], 3),
+                        rate=round(v['work'] / max(v['ms'], 1e-9) / (1e9 if v['bound'] == 'mfma' else 1e6), 2),
+                        unit='TFLOP/s' if v['bound'] == 'mfma' else 'GB/s') for k, v in prof.items()}
+
+    def leg(fn):
+        if rank == 0:
+            _lib.call('cvae_profile_enable', 1)
+        fn()
         torch.cuda.synchronize()
-        prof_t = profile_read(_lib.lib)
-        _lib.call('cvae_profile_enable', 0)
+        prof = profile_read(_lib.lib) if rank == 0 else None
+        if rank == 0:
+            _lib.call('cvae_profile_enable', 0)
+        return prof
+
+    log(rank, 'roofline legs')
+    prof_t = leg(lambda: [tr.train_step(batches[i]) for i in range(min(3, n_batches))])
+    prof_e = None if args.no_iw else leg(lambda: tr.iw_eval(ebatches[1:], args.iw_samples))
+    if rank == 0:
         roof_train = roofline_of(prof_t, 'train step (3 steps)')
         roof_all['train'] = table(prof_t)
         roof = roof_train
-        if not args.no_iw:
-            _lib.call('cvae_profile_enable', 1)
-            tr.iw_eval(ebatches[1:], args.iw_samples)
-            torch.cuda.synchronize()
-            prof_e = profile_read(_lib.lib)
-            _lib.call('cvae_profile_enable', 0)
+        if prof_e is not None:
             roof_eval = roofline_of(prof_e, 'IW-NLL evaluation (%d batches)' % args.iw_batches)
             roof_all['iw_nll'] = table(prof_e)
             t_train = sum(v['ms'] for v in prof_t.values()) / 3.0 * (args.steps + args.warmup)
@@ -264,6 +301,7 @@ def main():
             'iw_nll': iw, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
         }
         if world == 1 and not args.no_cpu_baseline:
+            log(rank, 'CPU baseline (oracle)')
             out['cpu_baseline'] = cpu_baseline(args, shape)
         print(json.dumps(out))
     if world > 1:

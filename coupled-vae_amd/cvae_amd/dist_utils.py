@@ -7,6 +7,10 @@
   arena, completed BEFORE the clip (Experiment.py:515 clips the full-batch gradient).
 * IW-NLL / MI: whole batches are sharded over ranks (MI depends on batch composition);
   only five (two) sums are reduced at the end.
+* IW-NLL, sample-sharded (`settings.shard_samples`, SURVEY.md 8e "preferred"): every rank sees the
+  same batch and the same eps (broadcast from rank 0), decodes K/N of the K samples, and the
+  (K/N, B) cross-entropy rows are all-gathered; every rank then reduces the full (K, B) table,
+  so test_lm returns identical (xent, nll, kl) everywhere and its caller is unchanged.
 """
 import torch
 import torch.distributed as dist
@@ -25,6 +29,11 @@ def allreduce_mean_(flat, n_buckets=1):
     separate async collectives (RCCL pipelines them over the xGMI links)."""
     w = world()
     if w == 1:
+        return flat
+    if flat.is_cuda and dist.get_backend() == 'gloo':   # CPU-side rehearsal / tests: stage through the host
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat.copy_(h.mul_(1.0 / w))
         return flat
     if n_buckets <= 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -48,5 +57,43 @@ def shard_batches(n_batches, r=None, w=None):
 def reduce_sums_(acc):
     """Sum a small tensor of partial sums over ranks (in place)."""
     if world() > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        if acc.is_cuda and dist.get_backend() == 'gloo':
+            h = acc.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            acc.copy_(h)
+        else:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     return acc
+
+
+def sample_slice(n_sample, r=None, w=None):
+    """[lo, hi) of the K importance samples rank r decodes (equal contiguous slices)."""
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    assert n_sample % w == 0, 'n_sample (%d) must be a multiple of the world size (%d)' % (n_sample, w)
+    k = n_sample // w
+    return r * k, (r + 1) * k
+
+
+def broadcast_(t, src=0):
+    if world() > 1:
+        if t.is_cuda and dist.get_backend() == 'gloo':
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
+    return t
+
+
+def allgather_rows(x):
+    """(k, ...) per rank -> (world*k, ...) in rank order, identical on every rank."""
+    w = world()
+    if w == 1:
+        return x
+    x = x.contiguous()
+    if x.is_cuda and dist.get_backend() == 'gloo':      # gloo gathers host tensors only (CPU-side tests)
+        return allgather_rows(x.cpu()).to(x.device)
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather(list(out.chunk(w, 0)), x)
+    return out

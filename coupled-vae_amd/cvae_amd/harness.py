@@ -172,8 +172,9 @@ class Trainer(object):
 
     # ---- evaluation: CV/Experiment.py:1323-1396 ; CC/Experiment.py:538-621
     def iw_eval(self, batches, n_sample):
-        """batches: iterable of batch dicts (this rank's shard).  Returns corpus metrics
-        (nll, xent, kl, ppl), identical on every rank."""
+        """batches: iterable of batch dicts -- this rank's shard, or with settings.shard_samples the
+        SAME batches on every rank (the K samples are sharded inside test_lm instead).  Returns
+        corpus metrics (nll, xent, kl, ppl), identical on every rank."""
         self.model.train(False)
         hp = self.hp
         acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # sum nll, xent, kl, len+1, count
@@ -192,7 +193,8 @@ class Trainer(object):
             acc += torch.stack([nll.sum().double(), xent.sum().double(), kl.sum().double(),
                                 (ln + 1).sum().double(), torch.tensor(float(nll.numel()), device=self.device).double()])
             per_sentence.append((xent, nll, kl))
-        dist_utils.reduce_sums_(acc)
+        if not settings.shard_samples:
+            dist_utils.reduce_sums_(acc)
         a = acc.tolist()
         self.model.train(True)
         return dict(nll=a[0] / a[4], xent=a[1] / a[4], kl=a[2] / a[4], ppl=math.exp(a[0] / a[3]),

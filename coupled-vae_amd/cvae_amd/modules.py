@@ -13,7 +13,7 @@ Out of scope: greedy / beam decoding branches.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import dist_utils, ops
 from .settings import settings
 
 
@@ -263,13 +263,18 @@ def _iw_nll(decoder, to_init_seq, go, eos, mu, sigma, mu_p, sigma_p, post_repr, 
     Z = mu.shape[1]
     dev = go.device
     eps = torch.cat([_noise.normal((n_chunk, B, Z), dev, 'iw_eps') for _ in range(n_sample // n_chunk)], 0)
+    sharded = settings.shard_samples and dist_utils.world() > 1
+    if sharded:
+        dist_utils.broadcast_(eps)                                      # one eps sequence for every rank
     z = ops.rsample_n(mu, sigma, eps)                                   # (K,B,Z)
-    kc = max(1, min(n_sample, settings.iw_max_rows // B))
-    xent = torch.empty((n_sample, B), dtype=torch.float32, device=dev)
+    k_lo, k_hi = dist_utils.sample_slice(n_sample) if sharded else (0, n_sample)
+    kc = max(1, min(k_hi - k_lo, settings.iw_max_rows // B))
+    xent = torch.empty((k_hi - k_lo, B), dtype=torch.float32, device=dev)
     plan = _sorted_plan(eos, pad) if settings.sort_eval and kc * B > ops.SKINNY_MAX_ROWS else None
     W, bias = decoder.ToVocab.weight, decoder.ToVocab.bias
-    for k0 in range(0, n_sample, kc):
-        k1 = min(n_sample, k0 + kc)
+    for k0 in range(k_lo, k_hi, kc):
+        k1 = min(k_hi, k0 + kc)
+        out = xent[k0 - k_lo:k1 - k_lo]
         if plan is not None and (k1 - k0) * B > ops.SKINNY_MAX_ROWS:
             order, live_sent = plan
             zz = z[k0:k1].index_select(1, order).transpose(0, 1).reshape(-1, Z)      # row b*(k1-k0) + k
@@ -279,14 +284,16 @@ def _iw_nll(decoder, to_init_seq, go, eos, mu, sigma, mu_p, sigma_p, post_repr, 
             go_s, eos_s = go.index_select(0, order), eos.index_select(0, order)
             final = decoder.final_states_sorted(init, go_s, live_sent)
             xs = ops.proj_ce_sorted(final, W, bias, eos_s, pad).view(B, k1 - k0)
-            xent[k0:k1].index_copy_(1, order, xs.t())
+            out.index_copy_(1, order, xs.t())
         else:
             zz = z[k0:k1].reshape(-1, Z)
             init = to_init(to_init_seq, zz)
             if post_repr is not None:
                 init = init + post_repr.repeat(k1 - k0, 1)
             final = decoder.final_states(init, go, False)
-            xent[k0:k1] = ops.proj_ce(final, W, bias, eos, pad).view(k1 - k0, B)
+            out.copy_(ops.proj_ce(final, W, bias, eos, pad).view(k1 - k0, B))
+    if sharded:
+        xent = dist_utils.allgather_rows(xent)
     xm, nll, kl = ops.iw_reduce(z, xent, mu, sigma, mu_p, sigma_p)
     return xm, nll, kl, z.transpose(0, 1)
 

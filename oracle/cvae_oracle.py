@@ -376,11 +376,7 @@ def normal_log_prob(x, mu, sigma):
     return -((x - mu) ** 2) / (2 * sigma * sigma) - torch.log(sigma) - math.log(math.sqrt(2 * math.pi))
 
 
-def iw_nll(P, model, cell, batch, eps):
-    """test_lm + importance_sampling (CV/Modules/vae_couple.py:504-578;
-    CC/Modules/vae_couple.py:274-364).  eps: (K,B,Z) = the K/2 chunk draws concatenated.
-    Returns xent, nll, kl (B,) and z (B,K,Z)."""
-    K = eps.shape[0]
+def _iw_setup(P, model, cell, batch):
     if not is_dialog(model):
         go, eos = batch['go'], batch['eos']
         last = encoder(P, 'Encoder.', cell, batch['bare'], batch['len'])
@@ -395,20 +391,41 @@ def iw_nll(P, model, cell, batch, eps):
         mu_p, sig_p, _ = gaussian(P, 'PriorGaussian.', post)
         mu, sigma, _ = gaussian(P, 'PosteriorGaussian.', torch.cat([resp, post], dim=1))
     init_pre = 'toInit.' if is_couple(model) else 'Decoder.toInit.'
-    xents, lpz, lqz, zs = [], [], [], []
-    for k0 in range(0, K, N_SAMPLE_CHUNK):
-        z = mu + sigma * eps[k0:k0 + N_SAMPLE_CHUNK]                      # (2,B,Z)
+    return go, eos, mu, sigma, mu_p, sig_p, post_repr, init_pre
+
+
+def iw_xent_rows(P, model, cell, batch, eps, lo=0, hi=None):
+    """Per-sample cross-entropy rows (hi-lo, B) of samples [lo, hi) of eps (K,B,Z): the decoder
+    half of importance_sampling (CV/Modules/vae_couple.py:540-557), in the reference's chunks of 2."""
+    go, eos, mu, sigma, _, _, post_repr, init_pre = _iw_setup(P, model, cell, batch)
+    hi = eps.shape[0] if hi is None else hi
+    xents = []
+    for k0 in range(lo, hi, N_SAMPLE_CHUNK):
+        z = mu + sigma * eps[k0:min(hi, k0 + N_SAMPLE_CHUNK)]             # (2,B,Z)
         n, B, Z = z.shape
         init = (to_init(P, init_pre, z) + post_repr).reshape(n * B, -1)
         final = decoder_final(P, 'Decoder.', cell, init, go.repeat(n, 1))
         xents.append(seq_xent(P, 'Decoder.', final, eos.repeat(n, 1)).view(n, B))
-        lpz.append(normal_log_prob(z, mu_p, sig_p).sum(2))
-        lqz.append(normal_log_prob(z, mu, sigma).sum(2))
-        zs.append(z)
-    xent, lpz, lqz, zs = torch.cat(xents), torch.cat(lpz), torch.cat(lqz), torch.cat(zs)
+    return torch.cat(xents)
+
+
+def iw_from_rows(P, model, cell, batch, eps, xent):
+    """The estimator half (CV/Modules/vae_couple.py:558-578) from the full (K,B) table."""
+    _, _, mu, sigma, mu_p, sig_p, _, _ = _iw_setup(P, model, cell, batch)
+    K = eps.shape[0]
+    z = mu + sigma * eps
+    lpz = normal_log_prob(z, mu_p, sig_p).sum(2)
+    lqz = normal_log_prob(z, mu, sigma).sum(2)
     nll = -(log_sum_exp(lpz - xent - lqz, 0) - math.log(K))
     kl = (lqz - lpz).mean(0)
-    return xent.mean(0), nll, kl, zs.transpose(0, 1)
+    return xent.mean(0), nll, kl, z.transpose(0, 1)
+
+
+def iw_nll(P, model, cell, batch, eps):
+    """test_lm + importance_sampling (CV/Modules/vae_couple.py:504-578;
+    CC/Modules/vae_couple.py:274-364).  eps: (K,B,Z) = the K/2 chunk draws concatenated.
+    Returns xent, nll, kl (B,) and z (B,K,Z)."""
+    return iw_from_rows(P, model, cell, batch, eps, iw_xent_rows(P, model, cell, batch, eps))
 
 
 def estimate_mi(P, cell, batch, eps):

@@ -3,7 +3,9 @@ dist_utils collectives around the CPU oracle's arithmetic.
 
 1. mean of per-rank gradients on half batches == full-batch gradient (what Trainer does with
    the flat gradient arena before the clip);
-2. sharded IW-NLL evaluation + one reduction of five sums == single-process corpus metrics."""
+2. sharded IW-NLL evaluation + one reduction of five sums == single-process corpus metrics;
+3. sample-sharded IW-NLL (eps broadcast, K/world samples per rank, all-gather of the cross-entropy
+   rows) == the single-process estimate, identical on every rank."""
 import math
 import os
 import sys
@@ -85,7 +87,21 @@ def _worker(rank, world, port, q):
         ref = eval_batches(range(nb))
         err2 = float((acc - ref).abs().max() / ref.abs().max())
         ppl = math.exp(acc[0] / acc[3])
-        q.put((rank, err, err2, ppl))
+        # sample-sharded IW-NLL (preferred): same batch and eps (broadcast from rank 0)
+        # everywhere, K/world samples decoded per rank, (K/world, B) rows all-gathered
+        K3 = 8
+        bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch(sents[:4], 12, True))
+        batch = dict(bare=bare, go=go, eos=eos, len=ln)
+        eps3 = torch.randn(K3, 4, Z, generator=torch.Generator().manual_seed(10 + rank))   # differs per rank
+        du.broadcast_(eps3)
+        lo, hi = du.sample_slice(K3)
+        with torch.no_grad():
+            rows = du.allgather_rows(O.iw_xent_rows(P, 'vae-couple', 'gru', batch, eps3, lo, hi))
+            got = O.iw_from_rows(P, 'vae-couple', 'gru', batch, eps3, rows)
+            eps_ref = torch.randn(K3, 4, Z, generator=torch.Generator().manual_seed(10))
+            want = O.iw_nll(P, 'vae-couple', 'gru', batch, eps_ref)
+        err3 = max(float((a - b).abs().max()) for a, b in zip(got[:3], want[:3]))
+        q.put((rank, err, err2, ppl, err3))
     finally:
         dist.destroy_process_group()
 
@@ -101,7 +117,8 @@ def test_dp_gradient_mean_and_sharded_eval_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, err2, ppl in res:
+    for rank, err, err2, ppl, err3 in res:
         assert err < 1e-5, ('gradient mean', rank, err)
         assert err2 < 1e-12, ('eval sums', rank, err2)
+        assert err3 < 1e-12, ('sample-sharded IW-NLL', rank, err3)
     assert abs(res[0][3] - res[1][3]) < 1e-9       # every rank ends with identical corpus metrics
