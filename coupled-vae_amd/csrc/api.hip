@@ -588,6 +588,15 @@ int cvae_kl_backward(const float* mu, const float* sigma, const float* mu_p, con
   CVAE_REQUIRE(mu && sigma && gkl && dmu && dsigma, "kl_backward: null operand");
   return launch_kl_bwd(mu, sigma, mu_p, sigma_p, gkl, B, Z, dmu, dsigma, dmu_p, dsigma_p, S(stream));
 }
+int cvae_kl_fb_forward(const float* mu, const float* sigma, int B, int Z, float floor, float* kl, void* stream) {
+  CVAE_REQUIRE(mu && sigma && kl, "kl_fb_forward: null operand");
+  return launch_kl_fb_fwd(mu, sigma, B, Z, floor, kl, S(stream));
+}
+int cvae_kl_fb_backward(const float* mu, const float* sigma, const float* gkl, int B, int Z, float floor,
+                        float* dmu, float* dsigma, void* stream) {
+  CVAE_REQUIRE(mu && sigma && gkl && dmu && dsigma, "kl_fb_backward: null operand");
+  return launch_kl_fb_bwd(mu, sigma, gkl, B, Z, floor, dmu, dsigma, S(stream));
+}
 int cvae_couple_forward(const float* init, const float* init_c, int B, int E, int Z, int euclid, float* d,
                         float* loss, void* stream) {
   CVAE_REQUIRE(init && init_c && d && loss, "couple_forward: null operand");

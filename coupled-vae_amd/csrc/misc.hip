@@ -412,6 +412,41 @@ int launch_kl_bwd(const float* mu, const float* sigma, const float* mu_p, const 
   return 0;
 }
 
+// Free bits (surprising-fix*, CV/Experiment.py:1137-1142): each latent dimension's KL to N(0,1) is
+// floored at `floor` before the sum; torch.clamp passes the gradient where kl_e >= floor.
+__device__ __forceinline__ float kl_std_elem(float m, float sg) { return 0.5f * (sg * sg + m * m - 1.f) - logf(sg); }
+__global__ __launch_bounds__(256) void kl_fb_fwd_kernel(int B, int Z, float floor, const float* __restrict__ mu,
+                                                        const float* __restrict__ sigma, float* __restrict__ kl) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int j = lane; j < Z; j += 64) acc += fmaxf(kl_std_elem(mu[(long)b * Z + j], sigma[(long)b * Z + j]), floor);
+  acc = wave_sum(acc);
+  if (lane == 0) kl[b] = acc;
+}
+__global__ void kl_fb_bwd_kernel(int B, int Z, float floor, const float* __restrict__ mu,
+                                 const float* __restrict__ sigma, const float* __restrict__ gkl,
+                                 float* __restrict__ dmu, float* __restrict__ dsigma) {
+  IDX1D((long)B * Z);
+  const float m = mu[idx], sg = sigma[idx];
+  const float g = (kl_std_elem(m, sg) >= floor) ? gkl[idx / Z] : 0.f;
+  dmu[idx] = g * m;
+  dsigma[idx] = g * (sg - 1.f / sg);
+}
+int launch_kl_fb_fwd(const float* mu, const float* sigma, int B, int Z, float floor, float* kl, hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(kl_fb_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, B, Z, floor, mu, sigma, kl);
+  CVAE_LAUNCH_CHECK("kl_fb_fwd_kernel");
+  return 0;
+}
+int launch_kl_fb_bwd(const float* mu, const float* sigma, const float* gkl, int B, int Z, float floor, float* dmu,
+                     float* dsigma, hipStream_t s) {
+  if ((long)B * Z == 0) return 0;
+  hipLaunchKernelGGL(kl_fb_bwd_kernel, GRID1D((long)B * Z), 0, s, B, Z, floor, mu, sigma, gkl, dmu, dsigma);
+  CVAE_LAUNCH_CHECK("kl_fb_bwd_kernel");
+  return 0;
+}
+
 __constant__ float kImqScales[7] = {.1f, .2f, .5f, 1.f, 2.f, 5.f, 10.f};
 
 __global__ __launch_bounds__(256) void couple_fwd_kernel(int B, int E, int Z, int euclid,

@@ -30,6 +30,9 @@ int launch_kl_fwd(const float* mu, const float* sigma, const float* mu_p, const 
                   float* kl, hipStream_t s);
 int launch_kl_bwd(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p, const float* gkl,
                   int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p, hipStream_t s);
+int launch_kl_fb_fwd(const float* mu, const float* sigma, int B, int Z, float floor, float* kl, hipStream_t s);
+int launch_kl_fb_bwd(const float* mu, const float* sigma, const float* gkl, int B, int Z, float floor, float* dmu,
+                     float* dsigma, hipStream_t s);
 int launch_couple_fwd(const float* a, const float* c, int B, int E, int Z, int euclid, float* d, float* loss,
                       hipStream_t s);
 int launch_couple_bwd(const float* a, const float* c, const float* d, const float* g, int B, int E, int Z,

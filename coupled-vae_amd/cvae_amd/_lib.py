@@ -50,6 +50,8 @@ SIGNATURES = {
     'cvae_reparam_backward': [P, P, I, I, P, P, P],
     'cvae_kl_forward': [P, P, P, P, I, I, P, P],
     'cvae_kl_backward': [P, P, P, P, P, I, I, P, P, P, P, P],
+    'cvae_kl_fb_forward': [P, P, I, I, F, P, P],
+    'cvae_kl_fb_backward': [P, P, P, I, I, F, P, P, P],
     'cvae_couple_forward': [P, P, I, I, I, I, P, P, P],
     'cvae_couple_backward': [P, P, P, P, I, I, I, I, P, P],
     'cvae_iw_reduce': [P, P, P, P, P, P, I, I, I, P, P, P, P],

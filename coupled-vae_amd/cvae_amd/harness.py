@@ -24,7 +24,10 @@ class HParams(object):
     def __init__(self, model='vae-couple', cell='gru', V=10002, E=200, H=128, Z=32, dropout=0.2, lr=1e-3,
                  beta1=0.9, beta2=0.999, clip_norm=30.0, kl_annealing=True, annealing_start=2000,
                  annealing_step=40000, lambda_couple=0.1, lambda_seq_couple=1.0, euclidean_dist=False,
-                 max_len=200, batch_size=32, pad_id=0):
+                 max_len=200, batch_size=32, pad_id=0, beta=0.8, cyc_M=4, cyc_R=0.5, lambda_fb=6.0):
+        """model: vae | vae-couple | cvae | cvae-couple, or a sibling on the same modules:
+        dae, beta-vae[-couple] (lambda_KL capped at beta), cyc-anneal-vae[-couple] (cyclic schedule, cyc_M
+        cycles with ramp fraction cyc_R), surprising-fix[-couple] (free bits lambda_fb)."""
         self.__dict__.update(locals())
         del self.__dict__['self']
 
@@ -36,10 +39,18 @@ class HParams(object):
 
 
 def lambda_kl(iter_num, hp):
-    """CV/Experiment.py:556."""
+    """Experiment.update_lambda_kl (CV/Experiment.py:524-558)."""
     if not hp.kl_annealing:
         return 1.0
-    return float(min(max(np.round((iter_num - hp.annealing_start) / hp.annealing_step, decimals=6), 0), 1))
+    if hp.model.startswith('cyc-anneal-vae'):
+        if iter_num < hp.annealing_start:
+            return 0.0
+        if iter_num > hp.annealing_step + hp.annealing_start:
+            return 1.0
+        tau = ((iter_num - hp.annealing_start) % int(hp.annealing_step / hp.cyc_M)) / (hp.annealing_step / hp.cyc_M)
+        return 1.0 if tau > hp.cyc_R else tau / hp.cyc_R
+    max_val = hp.beta if hp.model.startswith('beta-vae') else 1.0
+    return float(min(max(np.round((iter_num - hp.annealing_start) / hp.annealing_step, decimals=6), 0), max_val))
 
 
 def build_model(hp, device, seed=None):
@@ -132,6 +143,10 @@ class Trainer(object):
             else:
                 logits, prior, post = out
             kl = ops.kl_div(post.loc, post.scale, prior.loc, prior.scale)
+        elif hp.model == 'dae':                       # CV/Experiment.py:680-692: reconstruction loss only
+            logits, _ = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
+            seq = m.criterionSeq(logits, batch['eos'], keep_batch=True).mean(0)
+            return {'seq': seq, 'tot': seq, 'lambda_kl': 0.0}
         else:
             out = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
             eos = batch['eos']
@@ -139,7 +154,10 @@ class Trainer(object):
                 logits, post, _, _, logits_c, init, init_c = out
             else:
                 logits, post, _, _ = out
-            kl = ops.kl_div(post.loc, post.scale)
+            if hp.model.startswith('surprising-fix'):  # free bits, CV/Experiment.py:1141-1142
+                kl = ops.kl_free_bits(post.loc, post.scale, hp.lambda_fb / hp.Z)
+            else:
+                kl = ops.kl_div(post.loc, post.scale)
         res = {'seq': m.criterionSeq(logits, eos, keep_batch=True).mean(0), 'kl': kl.mean(0)}
         lam = lambda_kl(self.iter_num, hp)
         tot = res['seq'] + lam * res['kl']

@@ -392,6 +392,40 @@ class VAE(_TextBase):
         return logits, dist, z, None
 
 
+class DAE(_TextBase):
+    """CV/Modules/dae.py: deterministic auto-encoder on the same Encoder / Decoder (no posterior)."""
+
+    def __init__(self, hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                 WEAtt_type, encoder_emb, decoder_emb, pad_id):
+        super(DAE, self).__init__()
+        self._common(hid_dim, latent_dim, enc_layers, dec_layers, dropout, enc_bi, dec_max_len, beam_size,
+                     WEAtt_type, encoder_emb, decoder_emb)
+        self.Encoder = Encoder(self.emb_dim, hid_dim, enc_layers, dropout, enc_bi, encoder_emb)
+        self.toLatent = nn.Linear(hid_dim * self.n_dir * enc_layers, latent_dim)
+        self.Decoder = Decoder(with_init=True, **self._dec_kwargs(decoder_emb))
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+
+    def _latent(self, bare, sent_len):
+        last = self.Encoder.last_flat(bare, sent_len)
+        return ops.linear(last, self.toLatent.weight, self.toLatent.bias, ops.ACT_NONE)
+
+    def forward(self, go, sent_len=None, bare=None):
+        if not self.training:
+            raise NotImplementedError()
+        latent = self._latent(bare, sent_len)
+        return self.Decoder(None, to_init(self.Decoder.toInit, latent), go), latent
+
+    def test_lm(self, go, sent_len, bare, eos, n_sample):
+        """dae.py test_lm: one deterministic decode; nll = kl = +inf by the reference's definition."""
+        with torch.no_grad():
+            go, eos, bare = _truncate_eval(go, eos, bare, sent_len)
+            latent = self._latent(bare, sent_len)
+            final = self.Decoder.final_states(to_init(self.Decoder.toInit, latent), go, False)
+            xent = ops.proj_ce(final, self.Decoder.ToVocab.weight, self.Decoder.ToVocab.bias, eos, self.criterionSeq.pad)
+            inf = torch.full_like(xent, float('inf'))
+            return xent, xent + inf, inf, latent
+
+
 class VAE_COUPLE(_TextBase):
     """CV/Modules/vae_couple.py:374-741."""
 
@@ -515,4 +549,8 @@ class CVAE_COUPLE(_DialogBase):
         return logits, prior, dist, logits_c, init, init_c
 
 
-MODEL_CLASSES = {'vae': VAE, 'vae-couple': VAE_COUPLE, 'cvae': CVAE, 'cvae-couple': CVAE_COUPLE}
+# Experiment.__init__ (CV/Experiment.py:96-383) builds beta-vae*, cyc-anneal-vae* and surprising-fix* from the
+# very same VAE / VAE_COUPLE classes; they differ in the lambda_KL schedule / KL term (harness).
+MODEL_CLASSES = {'vae': VAE, 'vae-couple': VAE_COUPLE, 'cvae': CVAE, 'cvae-couple': CVAE_COUPLE, 'dae': DAE,
+                 'beta-vae': VAE, 'beta-vae-couple': VAE_COUPLE, 'cyc-anneal-vae': VAE,
+                 'cyc-anneal-vae-couple': VAE_COUPLE, 'surprising-fix': VAE, 'surprising-fix-couple': VAE_COUPLE}

@@ -436,6 +436,32 @@ def kl_div(mu, sigma, mu_p=None, sigma_p=None):
     return KLFn.apply(mu, sigma, mu_p, sigma_p)
 
 
+class KLFreeBitsFn(torch.autograd.Function):
+    """clamp(kl_divergence(N(mu,sigma) || N(0,1)), min=floor).sum(1) -> (B,)  (CV/Experiment.py:1137-1142)."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, floor):
+        mu, sigma = _c(mu), _c(sigma)
+        B, Z = mu.shape
+        kl = _f((B,), mu)
+        call('cvae_kl_fb_forward', ptr(mu), ptr(sigma), B, Z, float(floor), ptr(kl), stream())
+        ctx.floor = float(floor)
+        ctx.save_for_backward(mu, sigma)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        mu, sigma = ctx.saved_tensors
+        B, Z = mu.shape
+        dmu, dsigma = torch.empty_like(mu), torch.empty_like(mu)
+        call('cvae_kl_fb_backward', ptr(mu), ptr(sigma), ptr(_c(gkl)), B, Z, ctx.floor, ptr(dmu), ptr(dsigma), stream())
+        return dmu, dsigma, None
+
+
+def kl_free_bits(mu, sigma, floor):
+    return KLFreeBitsFn.apply(mu, sigma, floor)
+
+
 class CoupleFn(torch.autograd.Function):
     """euclidean(init, init_c.detach()) [+ IMQ]: CV/Experiment.py:742-751,1892-1923 -> (B,)."""
 

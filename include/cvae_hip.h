@@ -168,6 +168,12 @@ int cvae_kl_forward(const float* mu, const float* sigma, const float* mu_p, cons
 int cvae_kl_backward(const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
                      const float* gkl, int B, int Z, float* dmu, float* dsigma, float* dmu_p, float* dsigma_p,
                      void* stream);
+/* ---- f4 (sibling variant surprising-fix*, Experiment.py:1137-1142): free bits,
+ * kl[b] = sum_j max(KL(N(mu,sigma) || N(0,1))_j, floor), floor = lambda_fb / Z; the gradient passes
+ * where the element is >= floor (torch.clamp). */
+int cvae_kl_fb_forward(const float* mu, const float* sigma, int B, int Z, float floor, float* kl, void* stream);
+int cvae_kl_fb_backward(const float* mu, const float* sigma, const float* gkl, int B, int Z, float floor,
+                        float* dmu, float* dsigma, void* stream);
 /* ---- a10: euclidean + compute_imq_dist_couple (Experiment.py:742-751,1892-1923).
  * euclid != 0: loss[b] = d ; else loss[b] = -sum_s C_s/(C_s+d), C_s = 2*Z*s.  d[b] also out. */
 int cvae_couple_forward(const float* init, const float* init_c, int B, int E, int Z, int euclid, float* d,

@@ -242,8 +242,38 @@ def lambda_kl(iter_num, annealing_start, annealing_step, max_val=1.0):
                      max_val))
 
 
+def lambda_kl_model(iter_num, model, annealing_start, annealing_step, beta=1.0, M=4, R=0.5):
+    """Experiment.update_lambda_kl (CV/Experiment.py:524-558) for the variants that share the VAE
+    architecture: the linear ramp capped at 1 (vae*), at config.beta (beta-vae*), or the cyclic
+    schedule of cyc-anneal-vae* (M cycles inside the annealing window, ramp over the first R of each)."""
+    if model.startswith('cyc-anneal-vae'):
+        if iter_num < annealing_start:
+            return 0.0
+        if iter_num > annealing_step + annealing_start:
+            return 1.0
+        tau = ((iter_num - annealing_start) % int(annealing_step / M)) / (annealing_step / M)
+        return 1.0 if tau > R else tau / R
+    return lambda_kl(iter_num, annealing_start, annealing_step, beta if model.startswith('beta-vae') else 1.0)
+
+
+# Variants that reuse the VAE / VAE_COUPLE modules unchanged (CV/Experiment.py:147-173, 325-351):
+# only the lambda_KL schedule (beta-vae*, cyc-anneal-vae*) or the KL term (surprising-fix*:
+# free bits, Experiment.py:1141-1142) differs.
+ARCH = {'beta-vae': 'vae', 'beta-vae-couple': 'vae-couple', 'cyc-anneal-vae': 'vae',
+        'cyc-anneal-vae-couple': 'vae-couple', 'surprising-fix': 'vae', 'surprising-fix-couple': 'vae-couple'}
+
+
+def arch_of(model):
+    return ARCH.get(model, model)
+
+
 def is_couple(model):
     return model.endswith('couple')
+
+
+def kl_std_elem(mu, sigma):
+    """KL(N(mu,sigma) || N(0,1)) per latent dimension (torch.distributions.kl_divergence)."""
+    return 0.5 * (sigma * sigma + mu * mu - 1.0) - torch.log(sigma)
 
 
 def is_dialog(model):
@@ -253,20 +283,36 @@ def is_dialog(model):
 def train_forward(P, model, cell, batch, noise, cfg):
     """One teacher-forced training forward + loss assembly.
 
-    model: 'vae' | 'vae-couple' | 'cvae' | 'cvae-couple'.
+    model: 'vae' | 'vae-couple' | 'cvae' | 'cvae-couple' | 'dae', or a variant listed in ARCH.
     batch (text):   dict bare, go, eos, len            (int64 torch tensors)
     batch (dialog): dict post_bare, post_len, resp_bare, resp_go, resp_eos, resp_len
     noise: dict of masks / eps in the reference's draw layout (see make_golden.NOISE_ORDER);
            missing dropout masks mean dropout 0.
-    cfg: dict latent_dim, lambda_kl, lambda_couple, lambda_seq_couple, euclidean_dist.
+    cfg: dict latent_dim, lambda_kl, lambda_couple, lambda_seq_couple, euclidean_dist; optional
+         lambda_fb (free bits of surprising-fix*: each latent dimension's KL is floored at lambda_fb/Z).
     Returns dict with per-term losses, 'tot', and intermediate tensors."""
     out = {}
     g = noise.get
+    free_bits = cfg.get('lambda_fb') if model.startswith('surprising-fix') else None
+    model = arch_of(model)
+    if model == 'dae':
+        # DAE.forward (CV/Modules/dae.py): deterministic latent = toLatent(last), no KL term
+        go, eos = batch['go'], batch['eos']
+        last = encoder(P, 'Encoder.', cell, batch['bare'], batch['len'], g('enc_drop'))
+        latent = last @ P['toLatent.weight'].t() + P['toLatent.bias']
+        init = to_init(P, 'Decoder.toInit.', latent)
+        final = decoder_final(P, 'Decoder.', cell, init, go, g('dec_in_drop'), g('dec_out_drop'))
+        seq = seq_xent(P, 'Decoder.', final, eos)
+        out.update(latent=latent, init=init, final=final, seq_per_sent=seq, seq=seq.mean(0), tot=seq.mean(0))
+        return out
     if not is_dialog(model):
         go, eos = batch['go'], batch['eos']
         last = encoder(P, 'Encoder.', cell, batch['bare'], batch['len'], g('enc_drop'))
         mu, sigma, z = gaussian(P, 'PosteriorGaussian.', last, noise['eps'])
-        kl = kl_std(mu, sigma)
+        if free_bits is None:
+            kl = kl_std(mu, sigma)
+        else:
+            kl = torch.clamp(kl_std_elem(mu, sigma), min=free_bits / cfg['latent_dim']).sum(1)
         post_repr = 0.0
         couple_in = last
     else:
@@ -419,6 +465,15 @@ def iw_from_rows(P, model, cell, batch, eps, xent):
     nll = -(log_sum_exp(lpz - xent - lqz, 0) - math.log(K))
     kl = (lqz - lpz).mean(0)
     return xent.mean(0), nll, kl, z.transpose(0, 1)
+
+
+def dae_test_lm(P, cell, batch):
+    """DAE.test_lm (CV/Modules/dae.py): one deterministic teacher-forced decode -> xent (B,), latent (B,Z);
+    the reference returns nll = kl = +inf for this model."""
+    last = encoder(P, 'Encoder.', cell, batch['bare'], batch['len'])
+    latent = last @ P['toLatent.weight'].t() + P['toLatent.bias']
+    final = decoder_final(P, 'Decoder.', cell, to_init(P, 'Decoder.toInit.', latent), batch['go'])
+    return seq_xent(P, 'Decoder.', final, batch['eos']), latent
 
 
 def iw_nll(P, model, cell, batch, eps):

@@ -50,13 +50,23 @@ JOBS = [
     ('dialog_cvae-couple_gru_tiny', 'Coupled-CVAE', 'switchboard', 'cvae-couple', 'gru', TINY),
     ('dialog_cvae-couple_lstm_tiny', 'Coupled-CVAE', 'switchboard', 'cvae-couple', 'lstm', TINY),
     ('dialog_cvae_gru_tiny', 'Coupled-CVAE', 'switchboard', 'cvae', 'gru', TINY),
+    # sibling variants on the same encoder / decoder.  The annealing constants are
+    # substituted so that lambda_KL is live in the two recorded iterations: beta-vae sits at its
+    # cap (config.beta), the cyclic schedule is inside its first ramp.
+    ('text_beta-vae_gru_tiny', 'Coupled-VAE', 'ptb', 'beta-vae', 'gru',
+     dict(TINY, annealing_start=-10000000, annealing_step=10)),
+    ('text_cyc-anneal-vae-couple_lstm_tiny', 'Coupled-VAE', 'ptb', 'cyc-anneal-vae-couple', 'lstm',
+     dict(TINY, annealing_start=0, annealing_step=80)),
+    ('text_dae_gru_tiny', 'Coupled-VAE', 'ptb', 'dae', 'gru', TINY),
 ]
+BASE_MODEL = {'beta-vae': 'vae', 'cyc-anneal-vae': 'vae', 'cyc-anneal-vae-couple': 'vae-couple'}
 
 NOISE_ORDER = {
     # training-forward draw order (SURVEY 8a "RNG draw order")
     'vae': ['enc_drop', 'eps', 'dec_in_drop', 'dec_out_drop'],
     'vae-couple': ['enc_drop', 'eps', 'eps_couple', 'dec_in_drop', 'dec_out_drop',
                    'decc_in_drop', 'decc_out_drop'],
+    'dae': ['enc_drop', 'dec_in_drop', 'dec_out_drop'],
     'cvae': ['post_enc_drop', 'resp_enc_drop', 'eps_prior', 'eps', 'dec_in_drop', 'dec_out_drop'],
     'cvae-couple': ['post_enc_drop', 'resp_enc_drop', 'eps_prior', 'eps', 'eps_couple',
                     'dec_in_drop', 'dec_out_drop', 'decc_in_drop', 'decc_out_drop'],
@@ -114,6 +124,9 @@ def _patched_config_source(tree, dataset, model, cell, shp):
     src = src.replace('self.num_workers = 8', 'self.num_workers = 0')
     src = src.replace('self.use_tensorboard = True', 'self.use_tensorboard = False')
     src = src.replace('self.num_iters = 60000', 'self.num_iters = 2')
+    if 'annealing_start' in shp:
+        src = re.sub(r'self\.annealing_start = \d+', 'self.annealing_start = %d' % shp['annealing_start'], src)
+        src = re.sub(r'self\.annealing_step = \d+', 'self.annealing_step = %d' % shp['annealing_step'], src)
     return src
 
 
@@ -231,7 +244,9 @@ def child(name, tree, dataset, model, cell, shp, out_path):
                 lambda_couple=getattr(E.config, 'lambda_couple', 0.0),
                 lambda_seq_couple=getattr(E.config, 'lambda_seq_couple', 1),
                 euclidean_dist=bool(getattr(E.config, 'euclidean_dist', False)),
-                annealing_start=E.config.annealing_start, annealing_step=E.config.annealing_step,
+                annealing_start=getattr(E.config, 'annealing_start', 0),
+                annealing_step=getattr(E.config, 'annealing_step', 1),
+                beta=getattr(E.config, 'beta', 1.0), cyc_M=getattr(E.config, 'M', 0), cyc_R=getattr(E.config, 'R', 0.0),
                 dropout=E.config.dropout, clip_norm=E.config.clip_norm, lr=E.config.gen_lr,
                 torch_version=torch.__version__)
 
@@ -286,7 +301,7 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         trainable = list(exp.trainable_gen)
         _orig_step(scopes)
         w = {k: v.detach().clone() for k, v in ae.state_dict().items()}
-        steps.append((g, w, len(trainable), len({id(t) for t in trainable})))
+        steps.append((g, w, len(trainable), len({id(t) for t in trainable}), float(getattr(exp, 'lambda_KL', 0.0))))
 
     exp.step = rec_step
 
@@ -303,7 +318,8 @@ def child(name, tree, dataset, model, cell, shp, out_path):
     meta['n_train_steps'] = 2
     meta['trainable_entries'] = steps[0][2]
     meta['trainable_unique'] = steps[0][3]
-    names = NOISE_ORDER[model]
+    base = BASE_MODEL.get(model, model)
+    names = NOISE_ORDER[base]
     per = len(names)
     assert len(rec['noise']) == 2 * per, (len(rec['noise']), per)
     coupled = model.endswith('couple')
@@ -328,7 +344,10 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             assert (kind == 'eps') == nm.startswith('eps'), (nm, kind)
             out[p + 'noise/' + nm] = t.squeeze(0).numpy() if kind == 'eps' else t.numpy()
         fw = rec['fwd'][it]
-        if tree == 'Coupled-VAE':
+        if base == 'dae':
+            logits, dist = fw[0], None
+            out[p + 'latent'] = fw[1].detach().numpy()
+        elif tree == 'Coupled-VAE':
             logits, dist, z = fw[0], fw[1], fw[2]
             if coupled:
                 if not lean:
@@ -344,16 +363,18 @@ def child(name, tree, dataset, model, cell, shp, out_path):
                 out[p + 'init'], out[p + 'init_couple'] = fw[4].detach().numpy(), fw[5].detach().numpy()
         if not lean:
             out[p + 'logits'] = logits.detach().numpy()
-        out[p + 'mu'], out[p + 'sigma'] = dist.loc.detach().numpy(), dist.scale.detach().numpy()
+        if dist is not None:
+            out[p + 'mu'], out[p + 'sigma'] = dist.loc.detach().numpy(), dist.scale.detach().numpy()
         nseq = 2 if coupled else 1
         out[p + 'seq_per_sent'] = rec['seq'][it * nseq].numpy()
         if coupled:
             out[p + 'seq_c_per_sent'] = rec['seq'][it * nseq + 1].numpy()
             out[p + 'euc'] = rec['euc'][it].numpy()
-        out[p + 'kl_elem'] = rec['kl'][it].numpy()
+        if base != 'dae':
+            out[p + 'kl_elem'] = rec['kl'][it].numpy()
         out[p + 'tot'] = np.float64(rec['tot'][it])
-        out[p + 'lambda_kl'] = np.float64(0.0)   # iter 1,2 << annealing_start
-        g, w, _, _ = steps[it]
+        out[p + 'lambda_kl'] = np.float64(steps[it][4])   # 0 in the base fixtures: iter 1,2 << annealing_start
+        g, w = steps[it][0], steps[it][1]
         for k in keys_all:
             if g[k] is not None:
                 out[p + 'grad/' + k] = g[k].numpy()
@@ -362,9 +383,41 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         meta.setdefault('none_grad_keys', [k for k in keys_all if g[k] is None])
     rec['noise'].clear(); rec['seq'].clear(); rec['kl'].clear(); rec['euc'].clear()
 
+    def finish():
+        # lambda_KL schedule of this model at the SHIPPED annealing constants (Experiment.update_lambda_kl)
+        if tree == 'Coupled-VAE' and hasattr(E.config, 'kl_annealing'):
+            E.config.annealing_start, E.config.annealing_step = 2000, 40000
+            grid = [0, 1, 1999, 2000, 2001, 2500, 4000, 6999, 7000, 7001, 9500, 12000, 12001, 17000, 21999, 22000,
+                    22001, 30000, 41999, 42000, 42001, 50000, 10 ** 6]
+            vals = []
+            for it in grid:
+                exp.iter_num = it
+                exp.update_lambda_kl()
+                vals.append(float(exp.lambda_KL))
+            out['sched/iters'] = np.asarray(grid, dtype=np.int64)
+            out['sched/lambda'] = np.asarray(vals, dtype=np.float64)
+        out['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(out_path, **out)
+        print('wrote', out_path, '%.1f KB' % (os.path.getsize(out_path) / 1024))
+
+    from torch.utils.data import DataLoader
+    if base == 'dae':
+        # DAE.test_lm (Modules/dae.py): one deterministic decode, nll = kl = inf by construction
+        ae.train(False)
+        vb = next(iter(DataLoader(exp.val_set, batch_size=shp['B'], shuffle=False)))
+        bare, go, eos, ln = vb
+        with torch.no_grad():
+            xent, nll, kl, lat = ae.test_lm(bare=bare, sent_len=ln, go=go, eos=eos, n_sample=2)
+        assert bool(torch.isinf(nll).all()) and bool(torch.isinf(kl).all())
+        out['iw/dae/bare'], out['iw/dae/go'], out['iw/dae/eos'], out['iw/dae/len'] = \
+            bare.numpy(), go.numpy(), eos.numpy(), ln.numpy()
+        out['iw/dae/xent'], out['iw/dae/latent'] = xent.numpy(), lat.numpy()
+        sd_np('eval/')
+        finish()
+        return
+
     # ---- IW-NLL: test_lm on one val batch, K = 2 and K = 10 -----------------------
     ae.train(False)
-    from torch.utils.data import DataLoader
     vb = next(iter(DataLoader(exp.val_set, batch_size=shp['B'], shuffle=False)))
     with torch.no_grad():
         for K in (2, 10):
@@ -452,9 +505,7 @@ def child(name, tree, dataset, model, cell, shp, out_path):
     else:
         sd_np('eval/')
 
-    out['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    np.savez_compressed(out_path, **out)
-    print('wrote', out_path, '%.1f KB' % (os.path.getsize(out_path) / 1024))
+    finish()
 
 
 def main():

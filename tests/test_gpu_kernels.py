@@ -363,3 +363,26 @@ def test_clip_adam_alias_semantics(dev):
             assert abs(float(norm) - total) < 1e-4 * total
             ref = torch.cat([P['A.Embedding.weight'], P['rest']])
             assert float((pd.cpu() - ref).abs().max()) < 2e-6, (scale, step)
+
+
+def test_kl_free_bits(dev):
+    """surprising-fix* KL: clamp(kl_divergence(q, N(0,1)), min=lambda_fb/Z).sum(1), forward and gradient,
+    against torch.distributions in fp64 (the expression of CV/Experiment.py:1137-1142)."""
+    from cvae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, Z, floor = 37, 32, 6.0 / 32
+    mu = (torch.randn(B, Z, generator=g) * 0.8)
+    sigma = torch.rand(B, Z, generator=g) * 0.8 + 0.5
+    gk = torch.randn(B, generator=g)
+    m64, s64 = mu.double().requires_grad_(True), sigma.double().requires_grad_(True)
+    kl_e = torch.distributions.kl_divergence(torch.distributions.Normal(m64, s64),
+                                             torch.distributions.Normal(torch.zeros(Z, dtype=torch.float64),
+                                                                        torch.ones(Z, dtype=torch.float64)))
+    assert (kl_e < floor).any() and (kl_e > floor).any()
+    ref = torch.clamp(kl_e, min=floor).sum(1)
+    (ref * gk.double()).sum().backward()
+    md, sd = mu.to(dev).requires_grad_(True), sigma.to(dev).requires_grad_(True)
+    got = ops.kl_free_bits(md, sd, floor)
+    assert rel(got, ref) < 1e-5
+    (got * gk.to(dev)).sum().backward()
+    assert rel(md.grad, m64.grad) < 1e-5 and rel(sd.grad, s64.grad) < 1e-5

@@ -41,7 +41,8 @@ def make_trainer(g, dev, prefix='init/'):
                          dropout=m['dropout'], lr=m['lr'], clip_norm=m['clip_norm'],
                          annealing_start=m['annealing_start'], annealing_step=m['annealing_step'],
                          lambda_couple=m['lambda_couple'], lambda_seq_couple=m['lambda_seq_couple'],
-                         euclidean_dist=m['euclidean_dist'], max_len=m['max_len'], batch_size=m['B'])
+                         euclidean_dist=m['euclidean_dist'], max_len=m['max_len'], batch_size=m['B'],
+                         beta=m.get('beta', 0.8), cyc_M=m.get('cyc_M') or 4, cyc_R=m.get('cyc_R') or 0.5)
     model = harness.build_model(hp, 'cpu', seed=0)
     model.load_state_dict({k: g.t(prefix + k) for k in m['state_keys']}, strict=True)
     return harness.Trainer(hp, dev, model=model.to(dev))
@@ -60,8 +61,10 @@ def test_train_steps_match_reference(dev, name):
             batch = {k: v.to(dev) for k, v in g.batch(p).items()}
             modules.set_noise_source(modules.ReplayNoise(g.group(p + 'noise/')))
             res = tr.forward_backward(batch)
+            assert abs(res['lambda_kl'] - float(g.np(p + 'lambda_kl'))) < 1e-12   # schedule of the variant
             assert close(res['seq'], g.t(p + 'seq_per_sent').mean(), LOSS_TOL)
-            assert close(res['kl'], g.t(p + 'kl_elem').sum(1).mean(), LOSS_TOL)
+            if m['model'] != 'dae':
+                assert close(res['kl'], g.t(p + 'kl_elem').sum(1).mean(), LOSS_TOL)
             if O.is_couple(m['model']):
                 assert close(res['seq_c'], g.t(p + 'seq_c_per_sent').mean(), LOSS_TOL)
             assert close(res['tot'], g.np(p + 'tot'), LOSS_TOL)
@@ -101,7 +104,10 @@ def test_forward_outputs_match_reference(dev, name):
                 out = tr.model(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
                 logits, post = out[0], out[1]
                 extra = out[4:]
-        assert rel(post.loc, g.t(p + 'mu')) < 1e-4 and rel(post.scale, g.t(p + 'sigma')) < 1e-4
+        if m['model'] == 'dae':
+            assert rel(post, g.t(p + 'latent')) < 1e-4                 # (logits, latent_vector)
+        else:
+            assert rel(post.loc, g.t(p + 'mu')) < 1e-4 and rel(post.scale, g.t(p + 'sigma')) < 1e-4
         assert tuple(logits.shape) == tuple(g.np(p + 'logits').shape)
         assert rel(logits.materialize(), g.t(p + 'logits')) < 1e-4
         if O.is_couple(m['model']):
@@ -116,7 +122,21 @@ def _chunks(eps):
     return [eps[i:i + 2] for i in range(0, eps.shape[0], 2)]
 
 
-@pytest.mark.parametrize('name', names())
+VAES = [n for n in names() if '_dae_' not in n]          # fixtures with a posterior: IW-NLL, corpus loop, MI
+
+
+@pytest.mark.parametrize('name', [n for n in names() if '_dae_' in n])
+def test_dae_test_lm_matches_reference(dev, name):
+    g = Golden(name)
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    b = {k: v.to(dev) for k, v in g.batch('iw/dae/').items()}
+    xent, nll, kl, latent = tr.model.test_lm(bare=b['bare'], sent_len=b['len'], go=b['go'], eos=b['eos'], n_sample=2)
+    assert rel(xent, g.t('iw/dae/xent')) < LOSS_TOL and rel(latent, g.t('iw/dae/latent')) < LOSS_TOL
+    assert bool(torch.isinf(nll).all()) and bool(torch.isinf(kl).all())
+
+
+@pytest.mark.parametrize('name', VAES)
 def test_iw_nll_matches_reference(dev, name):
     from cvae_amd import modules
     g = Golden(name)
@@ -143,7 +163,7 @@ def test_iw_nll_matches_reference(dev, name):
         modules.set_noise_source(None)
 
 
-@pytest.mark.parametrize('name', names())
+@pytest.mark.parametrize('name', VAES)
 def test_corpus_metrics_match_reference(dev, name):
     """a1 + a13 + a16: raw ids -> device batches -> IW-NLL -> nll / xent / kl / ppl."""
     from cvae_amd import modules, data, harness
@@ -175,7 +195,7 @@ def test_corpus_metrics_match_reference(dev, name):
     assert close(got['kl'], g.np('corpus/kl'), 5e-4)
 
 
-@pytest.mark.parametrize('name', names('text_'))
+@pytest.mark.parametrize('name', [n for n in names('text_') if n in VAES])
 def test_mi_matches_reference(dev, name):
     from cvae_amd import modules
     g = Golden(name)
