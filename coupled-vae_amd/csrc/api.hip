@@ -389,6 +389,58 @@ int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, in
   return 0;
 }
 
+// ---- f3: greedy branch of Decoder.forward (CV/Modules/decoder.py:176-201; vae_couple.py:173-201).
+// Step-wise variant of the eval decoder: h_0 from the prefix step, then T times
+//   x_t = [emb(y_{t-1}), init] -> RNN step -> tanh(W_c h) -> ToVocab -> mask <unk> -> argmax -> y_t,
+// with y_{-1} = first[b].  The time-invariant half of the input projection (W_ih[:, E:] init) is
+// computed once.  Everything stays on the device; no host synchronisation between steps.
+int64_t cvae_decoder_greedy_scratch(int cell, int B, int T, int E, int Hd, int64_t V) {
+  const long G = gates_of(cell), RH = (long)B * Hd;
+  // xadd[2,B,G*Hd] + X[B,E] + xp[B,G*Hd] + hs[(T+2),B,Hd] + cs[(T+2),B,Hd] + final[B,E] + logits[B,V] + cur ids (int64)
+  return 3 * B * G * Hd + (long)B * E * 2 + 2 * (T + 2) * RH + (long)B * V + 2L * B + 64;
+}
+int cvae_decoder_greedy(int cell, int B, int T, int E, int Hd, int64_t V, const float* init, const int64_t* first,
+                        const float* emb, const float* const* w, const float* W_v, const float* b_v, int mask_id,
+                        float* ws, int64_t* out_ids, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_greedy: bad cell");
+  CVAE_REQUIRE(B > 0 && B <= SKINNY_MAX_ROWS && T > 0 && E > 0 && Hd > 0 && V > 0 && V <= INT_MAX,
+               "decoder_greedy: bad shape B=%d T=%d E=%d Hd=%d (B <= %d)", B, T, E, Hd, SKINNY_MAX_ROWS);
+  CVAE_REQUIRE(init && first && emb && w && W_v && b_v && ws && out_ids, "decoder_greedy: null operand");
+  const int G = gates_of(cell);
+  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* b_ih = w[2]; const float* b_hh = w[3];
+  const float* W_c = w[4]; const float* b_c = w[5];
+  const long RH = (long)B * Hd, GH = (long)G * Hd;
+  float* xinit = ws;                        // [B, G*Hd]  W_ih[:, E:] init
+  float* x0 = xinit + B * GH;               // [B, G*Hd]  W_ih[:, :E] init + b_ih (prefix step)
+  float* xp = x0 + B * GH;                  // [B, G*Hd]  W_ih[:, :E] emb(y_{t-1}) + b_ih
+  float* X = xp + B * GH;                   // [B, E]
+  float* fin = X + (long)B * E;             // [B, E]
+  float* hs = fin + (long)B * E;            // [(T+2), B, Hd]
+  float* cs = hs + (T + 2) * RH;            // [(T+2), B, Hd]
+  float* logits = cs + (T + 2) * RH;        // [B, V]
+  uintptr_t cp = reinterpret_cast<uintptr_t>(logits + (long)B * V);
+  int64_t* cur = reinterpret_cast<int64_t*>((cp + 15) & ~uintptr_t(15));    // [B]
+  CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, B, (int)GH, E, xinit, s));
+  CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, B, (int)GH, E, x0, s));
+  RnnFwd f = {};
+  f.cell = cell; f.T = 1; f.R = B; f.H = Hd; f.xproj = x0; f.xmod = B; f.xadd = xinit;
+  f.W_hh = W_hh; f.b_hh = b_hh; f.hs = hs; f.cs = cell == CELL_LSTM ? cs : nullptr;
+  CVAE_TRY(launch_rnn_forward(f, s));                                      // h_0 (slot 1) from zeros (slot 0)
+  f.xproj = xp; f.init_in_place = 1;
+  CVAE_TRY(launch_copy(reinterpret_cast<float*>(cur), reinterpret_cast<const float*>(first), 2L * B, s));
+  for (int t = 0; t < T; ++t) {
+    CVAE_TRY(launch_embed(1, B, E, 0, 0, cur, B, emb, nullptr, nullptr, nullptr, X, s));
+    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, B, (int)GH, E, xp, s));
+    f.hs = hs + (t + 1) * RH; f.cs = cell == CELL_LSTM ? cs + (t + 1) * RH : nullptr;
+    CVAE_TRY(launch_rnn_forward(f, s));
+    CVAE_TRY(linear_nt(hs + (t + 2) * RH, W_c, Hd, b_c, ACT_TANH, B, E, Hd, fin, s));
+    CVAE_TRY(linear_nt(fin, W_v, E, b_v, ACT_NONE, B, (int)V, E, logits, s));
+    CVAE_TRY(launch_argmax_rows(B, (int)V, logits, V, mask_id, out_ids, T, t, cur, s));
+  }
+  return 0;
+}
+
 int cvae_decoder_forward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const float* const* init,
                            const int64_t* go, const float* emb, const float* const* mask_in,
                            const float* const* mask_out, const float* const* w, float* const* X,

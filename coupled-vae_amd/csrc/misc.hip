@@ -312,6 +312,47 @@ int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hip
   return 0;
 }
 
+// Greedy decoding (CV/Modules/decoder.py:176-201): index of the row maximum, entry `mask_id` excluded
+// (the reference sets the <unk> logit to -inf first); ties go to the lowest index, as torch.argmax.
+// One block per row.  Writes the id to out[b*out_ld + out_off] and to cur[b] (next step's input).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(int V, const float* __restrict__ logits, long ld,
+                                                          int mask_id, int64_t* __restrict__ out, long out_ld,
+                                                          long out_off, int64_t* __restrict__ cur) {
+  __shared__ float smax[4];
+  __shared__ int sidx[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (long)b * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const float x = (v == mask_id) ? -INFINITY : row[v];
+    if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_down(best, off, 64);
+    const int oi = __shfl_down(bi, off, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { smax[wave] = best; sidx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
+    out[(long)b * out_ld + out_off] = bi;
+    cur[b] = bi;
+  }
+}
+int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, int64_t* out, long out_ld, long out_off,
+                       int64_t* cur, hipStream_t s) {
+  if (B == 0) return 0;
+  CVAE_REQUIRE(V > 0 && (V > 1 || mask_id != 0), "argmax_rows: nothing to choose from");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, s, V, logits, ld, mask_id, out, out_ld, out_off, cur);
+  CVAE_LAUNCH_CHECK("argmax_rows_kernel");
+  return 0;
+}
+
 // logits[b, t, v] = tmp[t*B + b, v]
 __global__ void logits_bt_kernel(int T, int B, long V, const float* __restrict__ tmp, float* __restrict__ out) {
   IDX1D((long)T * B * V);

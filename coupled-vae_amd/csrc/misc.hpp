@@ -22,6 +22,8 @@ int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* 
                      hipStream_t s);
 int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s);
 int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s);
+int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, int64_t* out, long out_ld,
+                       long out_off, int64_t* cur, hipStream_t s);
 int launch_logits_bt(int T, int B, long V, const float* tmp, float* out, hipStream_t s);
 int launch_reparam_fwd(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
                        hipStream_t s);

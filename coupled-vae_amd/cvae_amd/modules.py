@@ -196,9 +196,22 @@ class Decoder(nn.Module):
         cell = ops.LSTM if self.use_lstm else ops.GRU
         return ops.decoder_sorted(cell, init_input, helper, live_sent, self.Embedding.weight, w)
 
+    def greedy(self, init_input, helper):
+        """Greedy branch (CV/Modules/decoder.py:176-201; vae_couple.py:173-201): max_len steps from
+        helper[:, 0], <unk> (id 3) masked as in the reference (test_non_unk).  -> ids (B, max_len)."""
+        rnn = self.LSTM if self.use_lstm else self.GRU
+        w = _rnn_weights(rnn) + [self.W_c.weight, self.W_c.bias]
+        cell = ops.LSTM if self.use_lstm else ops.GRU
+        return ops.decoder_greedy(cell, init_input, helper[:, 0], self.max_len, self.Embedding.weight, w,
+                                  self.ToVocab.weight, self.ToVocab.bias, mask_id=3)
+
     def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None):
         if not (self.training or test_lm):
-            raise NotImplementedError('greedy / beam decoding is outside the accelerated hot path (SURVEY 8f.3)')
+            if self.beam_size > 1:
+                raise NotImplementedError('beam search is not accelerated (every shipped config uses beam_size 1)')
+            ids = self.greedy(init_input, helper)
+            # the reference's return format: per sentence, a list of max_len tensors of shape (1,)
+            return [[ids[b, t:t + 1] for t in range(ids.shape[1])] for b in range(ids.shape[0])]
         n_sent = helper.shape[0] if _n_sent is None else _n_sent
         final = self.final_states(init_input, helper[:n_sent], self.training and not test_lm, _noise_prefix)
         return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, n_sent)
@@ -343,6 +356,21 @@ class _TextBase(nn.Module):
     def _to_init_seq(self):
         return self.toInit if hasattr(self, 'toInit') else self.Decoder.toInit
 
+    def decode_ids(self, latents, go):
+        """decode_from (CV/Modules/vae_couple.py:681-696) as an id tensor (B, max_len)."""
+        with torch.no_grad():
+            return self.Decoder.greedy(to_init(self._to_init_seq(), latents), go)
+
+    def decode_from(self, latents, go):
+        """CV/Modules/vae_couple.py:681-696 / vae.py:299: greedy decode of given latents, reference format."""
+        ids = self.decode_ids(latents, go)
+        return [[ids[b, t:t + 1] for t in range(ids.shape[1])] for b in range(ids.shape[0])]
+
+    def sample_from_prior(self, go):
+        """CV/Modules/vae_couple.py:635-655: z ~ N(0, I) then greedy decode."""
+        z = _noise.normal((go.shape[0], self.latent_dim), go.device, 'prior_z')
+        return self.decode_from(z, go)
+
     def estimate_mi(self, go, sent_len, bare, n_sample):
         """CV/Modules/vae_couple.py:453-502 -> (mi (B,), z (B,K,Z))."""
         with torch.no_grad():
@@ -410,8 +438,10 @@ class DAE(_TextBase):
         return ops.linear(last, self.toLatent.weight, self.toLatent.bias, ops.ACT_NONE)
 
     def forward(self, go, sent_len=None, bare=None):
-        if not self.training:
-            raise NotImplementedError()
+        if not self.training:                     # dae.py forward, eval branch: decode a prior sample greedily
+            latent = _noise.normal((go.shape[0], self.latent_dim), go.device, 'prior_z')
+            with torch.no_grad():
+                return self.Decoder(None, to_init(self.Decoder.toInit, latent), go)
         latent = self._latent(bare, sent_len)
         return self.Decoder(None, to_init(self.Decoder.toInit, latent), go), latent
 

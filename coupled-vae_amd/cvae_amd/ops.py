@@ -235,6 +235,22 @@ def decoder_sorted(cell, init, go, live_sent, emb, w):
         return final
 
 
+def decoder_greedy(cell, init, first, T, emb, w, W_v, b_v, mask_id=3):
+    """Greedy decoding (CV/Modules/decoder.py:176-201): init (B,E), first (B,) <go> ids, w = [W_ih, W_hh, b_ih,
+    b_hh, W_c, b_c], ToVocab (W_v, b_v); entry mask_id (<unk>) never chosen.  -> ids (B,T) int64."""
+    with torch.no_grad():
+        init, first, emb, W_v, b_v = _c(init), _c(first), _c(emb), _c(W_v), _c(b_v)
+        w = [_c(t) for t in w]
+        B, E = init.shape
+        V, Hd = emb.shape[0], w[1].shape[1]
+        ws = _f((query('cvae_decoder_greedy_scratch', cell, B, T, E, Hd, V),), emb)
+        out = torch.empty((B, T), dtype=torch.int64, device=emb.device)
+        warr = ptr_array(w)
+        call('cvae_decoder_greedy', cell, B, T, E, Hd, V, ptr(init), ptr(first), ptr(emb), warr, ptr(W_v), ptr(b_v),
+             int(mask_id), ptr(ws), ptr(out), stream())
+        return out
+
+
 class DecoderPairFn(torch.autograd.Function):
     """Two training decoders of identical shape (Decoder / DecoderCouple) advanced in lock-step:
     every timestep of both recurrences is one launch (cvae_decoder_forward_n).

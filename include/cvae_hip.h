@@ -102,6 +102,16 @@ int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, in
                                 const int64_t* go, const float* emb, const int* live_sent, const float* const* w,
                                 float* X, float* xproj, float* xadd, float* hp, float* hs, float* cs, float* final,
                                 void* stream);
+/* ---- f3: greedy branch of Decoder.forward (Modules/decoder.py:176-201, Modules/vae_couple.py:
+ * 173-201; used by sample_from_prior / decode_from / gen_interps).  T = max_len steps, no early stop
+ * (as the reference): y_t = argmax_v ToVocab(tanh(W_c h_t))[v] with entry mask_id set to -inf first
+ * (the reference masks <unk> = 3; pass -1 for no mask), ties to the lowest id.  first[B]: the <go>
+ * ids (helper[:, 0]).  out_ids[B,T] int64.  ws: cvae_decoder_greedy_scratch(...) floats, 16-byte
+ * aligned.  B <= 256.  Dropout is off (eval mode), as in every caller of this branch. */
+int64_t cvae_decoder_greedy_scratch(int cell, int B, int T, int E, int Hd, int64_t V);
+int cvae_decoder_greedy(int cell, int B, int T, int E, int Hd, int64_t V, const float* init, const int64_t* first,
+                        const float* emb, const float* const* w, const float* W_v, const float* b_v, int mask_id,
+                        float* ws, int64_t* out_ids, void* stream);
 int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd);
 /* dfinal[T,B,E] -> dinit[B,E] (overwritten), dw[6] (overwritten), demb[V,E] (ACCUMULATED). */
 int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,

@@ -467,6 +467,44 @@ def iw_from_rows(P, model, cell, batch, eps, xent):
     return xent.mean(0), nll, kl, z.transpose(0, 1)
 
 
+def decoder_greedy(P, prefix, cell, init, first, T, mask_id=3):
+    """Greedy branch of Decoder.forward (CV/Modules/decoder.py:176-201; vae_couple.py:173-201), eval mode:
+    h_0 from the prefix step on [init, init]; then T steps of [emb(y_{t-1}), init] -> cell -> tanh(W_c h)
+    -> ToVocab -> logit[mask_id] = -inf -> argmax.  init (B,E), first (B,) -> ids (B,T) int64."""
+    cn = 'GRU' if cell == 'gru' else 'LSTM'
+    W_ih, W_hh = P[prefix + cn + '.weight_ih_l0'], P[prefix + cn + '.weight_hh_l0']
+    b_ih, b_hh = P[prefix + cn + '.bias_ih_l0'], P[prefix + cn + '.bias_hh_l0']
+    emb = P[prefix + 'Embedding.weight']
+    B = init.shape[0]
+    H = W_hh.shape[1]
+    h = torch.zeros(B, H, dtype=init.dtype)
+    c = torch.zeros(B, H, dtype=init.dtype)
+
+    def step(x, h, c):
+        gi, gh = x @ W_ih.t() + b_ih, h @ W_hh.t() + b_hh
+        if cell == 'gru':
+            ir, iz, inn = gi.chunk(3, 1)
+            hr, hz, hn = gh.chunk(3, 1)
+            r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+            n = torch.tanh(inn + r * hn)
+            return (1 - z) * n + z * h, c
+        i, f, g, o = (gi + gh).chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        return torch.sigmoid(o) * torch.tanh(c), c
+
+    h, c = step(torch.cat([init, init], 1), h, c)
+    cur, out = first, []
+    for _ in range(T):
+        h, c = step(torch.cat([emb[cur], init], 1), h, c)
+        final = torch.tanh(h @ P[prefix + 'W_c.weight'].t() + P[prefix + 'W_c.bias'])
+        logits = final @ P[prefix + 'ToVocab.weight'].t() + P[prefix + 'ToVocab.bias']
+        if mask_id is not None and mask_id >= 0:
+            logits[:, mask_id] = -float('inf')
+        cur = torch.argmax(logits, dim=1)
+        out.append(cur)
+    return torch.stack(out, 1)
+
+
 def dae_test_lm(P, cell, batch):
     """DAE.test_lm (CV/Modules/dae.py): one deterministic teacher-forced decode -> xent (B,), latent (B,Z);
     the reference returns nll = kl = +inf for this model."""

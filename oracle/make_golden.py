@@ -502,6 +502,16 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             eps = [t for kind, t in rec['noise'] if kind == 'eps' and t.shape[0] == 2]
             out['mi/B%d/eps' % Bm] = torch.cat(eps, 0).numpy()
             out['mi/B%d/mi' % Bm] = mi.numpy()
+        # ---- greedy decoding (8f.3): decode_from on fixed latents, max_len steps, <unk> masked ----
+        ae.train(False)
+        gen = torch.Generator().manual_seed(77)
+        lat = torch.randn(shp['B'], shp['Z'], generator=gen)
+        go1 = torch.zeros(shp['B'], 1, dtype=torch.long) + exp.test_set.go
+        with torch.no_grad():
+            sents_g = ae.decode_from(lat, go1)
+        out['greedy/latents'], out['greedy/go'] = lat.numpy(), go1.numpy()
+        out['greedy/ids'] = np.asarray([[int(t.item()) for t in srow] for srow in sents_g], dtype=np.int64)
+        meta['greedy_steps'] = int(out['greedy/ids'].shape[1])
     else:
         sd_np('eval/')
 

@@ -122,6 +122,46 @@ def _chunks(eps):
     return [eps[i:i + 2] for i in range(0, eps.shape[0], 2)]
 
 
+@pytest.mark.parametrize('name', [n for n in names('text_') if 'greedy/ids' in Golden(n)])
+def test_greedy_decode_matches_reference(dev, name):
+    """8f.3: decode_from on the recorded latents -> the reference's token ids, bit-exact; and the
+    reference's return format (per sentence a list of max_len (1,) tensors)."""
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    lat, go = g.t('greedy/latents').to(dev), g.t('greedy/go').to(dev)
+    ids = tr.model.decode_ids(lat, go)
+    assert ids.dtype == torch.int64 and torch.equal(ids.cpu(), g.t('greedy/ids'))
+    sents = tr.model.decode_from(lat, go)
+    assert len(sents) == m['B'] and len(sents[0]) == m['max_len'] and tuple(sents[0][0].shape) == (1,)
+    assert int(sents[2][5]) == int(g.np('greedy/ids')[2, 5])
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+def test_greedy_decode_vs_oracle_ptb_shape(dev, cell):
+    """PTB shape, 82 steps x 32 sentences.  A near-tie between the two best logits could legitimately flip
+    an id between fp32 summation orders and change the rest of that sentence, so the check is: every
+    sentence equals the oracle's up to its first difference, and at a difference the oracle's own top-2
+    logit gap is below 1e-4 (none is expected with these seeds)."""
+    from cvae_amd import data, harness
+    s = dict(data.SHAPES['ptb'])
+    s['V'] = 3000
+    hp = harness.HParams(model='vae-couple', cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'], max_len=82)
+    tr = harness.Trainer(hp, dev, seed=5)
+    tr.model.train(False)
+    B = 32
+    lat = torch.randn(B, s['Z'], generator=torch.Generator().manual_seed(9))
+    go = torch.full((B, 1), 1, dtype=torch.int64)
+    ids = tr.model.decode_ids(lat.to(dev), go.to(dev)).cpu()
+    assert tuple(ids.shape) == (B, 82) and not (ids == 3).any()
+    P = O.tie_aliases({k: v.detach().cpu().double() for k, v in tr.model.state_dict().items()})
+    with torch.no_grad():
+        ref = O.decoder_greedy(P, 'Decoder.', cell, O.to_init(P, 'toInit.', lat.double()), go[:, 0], 82)
+    n_diff = int((ids != ref).any(1).sum())
+    assert n_diff == 0, '%d sentences differ from the fp64 oracle' % n_diff
+
+
 VAES = [n for n in names() if '_dae_' not in n]          # fixtures with a posterior: IW-NLL, corpus loop, MI
 
 
