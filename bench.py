@@ -229,6 +229,30 @@ def main():
     train_tok_s = float(tok.item()) / dt
     log(rank, 'training done: %.3f ms/step' % (dt / max(args.steps, 1) * 1e3))
 
+    # ---- informational: the same corpus with length-bucketed batches from the device-resident corpus
+    # (batch composition differs from the reference's plain shuffle, so this is NOT `value`)
+    corpus.to_device(dev)
+    order = data.epoch_batches(corpus.lengths, B, seed=7 + rank, bucket=True, drop_last=True)
+    bb = [dict(zip(('bare', 'go', 'eos', 'len'), corpus.batch_resident(ix))) for ix in order[:n_batches]]
+    btok = [corpus.n_tokens(ix) for ix in order[:n_batches]]
+    for i in range(min(args.warmup, len(bb))):
+        tr.train_step(bb[i])
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, len(bb)):
+        tr.train_step(bb[i])
+    barrier_sync(world)
+    dt_b = max_over_ranks(time.perf_counter() - t0, world, dev)
+    tok_b = torch.tensor([float(sum(btok[args.warmup:]))], dtype=torch.float64, device=dev)
+    if world > 1:
+        if dist.get_backend() == 'gloo':
+            tok_b = tok_b.cpu()
+        dist.all_reduce(tok_b)
+    bucketed = dict(value=round(float(tok_b.item()) / max(dt_b, 1e-9), 1), unit='tokens/s',
+                    ms_per_step=round(dt_b / max(len(bb) - args.warmup, 1) * 1e3, 3),
+                    note='length-bucketed batches (pool 50 x batch), same sentences; informational')
+    log(rank, 'bucketed training: %.3f ms/step' % bucketed['ms_per_step'])
+
     # ---- IW-NLL evaluation (test.py path): sentences sharded over ranks
     iw = None
     if not args.no_iw:
@@ -298,7 +322,7 @@ def main():
                                    % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
                                       shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
                        'parallelism': 'dp%d' % world},
-            'iw_nll': iw, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
+            'iw_nll': iw, 'train_bucketed': bucketed, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
         }
         if world == 1 and not args.no_cpu_baseline:
             log(rank, 'CPU baseline (oracle)')

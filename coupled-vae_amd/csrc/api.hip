@@ -139,8 +139,15 @@ int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* t
 int cvae_pack_batch(const int64_t* raw_flat, const int64_t* raw_offsets, int B, int max_len, int width,
                     int64_t pad, int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out,
                     int64_t* len, void* stream) {
-  return launch_pack_batch(raw_flat, raw_offsets, B, max_len, width, pad, go, eos, bare, go_out, eos_out, len,
-                           S(stream));
+  return launch_pack_batch(raw_flat, raw_offsets, nullptr, B, max_len, width, pad, go, eos, bare, go_out, eos_out,
+                           len, S(stream));
+}
+int cvae_pack_batch_indexed(const int64_t* corpus_flat, const int64_t* corpus_offsets, const int64_t* sel, int B,
+                            int max_len, int width, int64_t pad, int64_t go, int64_t eos, int64_t* bare,
+                            int64_t* go_out, int64_t* eos_out, int64_t* len, void* stream) {
+  CVAE_REQUIRE(sel || B == 0, "pack_batch_indexed: null index vector");
+  return launch_pack_batch(corpus_flat, corpus_offsets, sel, B, max_len, width, pad, go, eos, bare, go_out, eos_out,
+                           len, S(stream));
 }
 
 int cvae_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, void* stream) {

@@ -14,14 +14,18 @@ namespace cvae {
   if (idx >= (long)(n)) return;
 
 // ------------------------------------------------------------------ a1 / a2
-__global__ void pack_batch_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ off, int B,
+// sel == null: sentence b of the batch is CSR row b; otherwise CSR row sel[b] of a corpus that is
+// resident on the device (8f.2: a batch then costs one copy of B indices, no token traffic).
+__global__ void pack_batch_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ off,
+                                  const int64_t* __restrict__ sel, int B,
                                   int max_len, int width, int64_t pad, int64_t go, int64_t eos,
                                   int64_t* __restrict__ bare, int64_t* __restrict__ go_out,
                                   int64_t* __restrict__ eos_out, int64_t* __restrict__ len) {
   IDX1D((long)B * (width + 1));
   const int b = (int)(idx / (width + 1)), j = (int)(idx % (width + 1));
-  const int64_t beg = off[b];
-  int64_t l = off[b + 1] - beg;
+  const int64_t row = sel ? sel[b] : b;
+  const int64_t beg = off[row];
+  int64_t l = off[row + 1] - beg;
   if (l > max_len) l = max_len;
   if (j == 0) len[b] = l;
   // bare[j] = id_j | pad ; go[j] = go, id_{j-1} | pad ; eos[j] = id_j, eos at j == l | pad
@@ -30,13 +34,13 @@ __global__ void pack_batch_kernel(const int64_t* __restrict__ flat, const int64_
   eos_out[(long)b * (width + 1) + j] = j < l ? flat[beg + j] : (j == l ? eos : pad);
 }
 
-int launch_pack_batch(const int64_t* flat, const int64_t* off, int B, int max_len, int width, int64_t pad,
+int launch_pack_batch(const int64_t* flat, const int64_t* off, const int64_t* sel, int B, int max_len, int width, int64_t pad,
                       int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out, int64_t* len,
                       hipStream_t s) {
   CVAE_REQUIRE(B >= 0 && max_len >= 0 && width >= 0 && width <= max_len, "pack_batch: bad shape");
   if (B == 0) return 0;
   CVAE_REQUIRE(flat && off && bare && go_out && eos_out && len, "pack_batch: null operand");
-  hipLaunchKernelGGL(pack_batch_kernel, GRID1D((long)B * (width + 1)), 0, s, flat, off, B, max_len, width, pad, go,
+  hipLaunchKernelGGL(pack_batch_kernel, GRID1D((long)B * (width + 1)), 0, s, flat, off, sel, B, max_len, width, pad, go,
                      eos, bare, go_out, eos_out, len);
   CVAE_LAUNCH_CHECK("pack_batch_kernel");
   return 0;

@@ -4,7 +4,7 @@
 
 namespace cvae {
 
-int launch_pack_batch(const int64_t* flat, const int64_t* off, int B, int max_len, int width, int64_t pad,
+int launch_pack_batch(const int64_t* flat, const int64_t* off, const int64_t* sel, int B, int max_len, int width, int64_t pad,
                       int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out, int64_t* len,
                       hipStream_t s);
 int launch_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, hipStream_t s);

@@ -25,6 +25,7 @@ SIGNATURES = {
     'cvae_version': [],
     'cvae_init': [I],
     'cvae_pack_batch': [P, P, I, I, I, L, L, L, P, P, P, P, P],
+    'cvae_pack_batch_indexed': [P, P, P, I, I, I, L, L, L, P, P, P, P, P],
     'cvae_sort_resort': [P, I, P, P, P],
     'cvae_gemm': [I, I, I, I, I, P, L, P, L, P, L, P, I, I, P],
     'cvae_linear_forward': [P, P, P, I, I, I, I, P, P],

@@ -51,6 +51,50 @@ class Corpus(object):
             flat_d = torch.zeros((1,), dtype=torch.int64, device=device)
         return ops.pack_batch(flat_d, off_d, self.max_len, width, PAD, GO, EOS)
 
+    # ---- 8f.2: the whole corpus resident on the device; a batch costs one copy of B indices
+    def to_device(self, device):
+        flat = np.concatenate(self.sentences) if self.sentences else np.zeros((1,), np.int64)
+        off = np.cumsum([0] + [len(s) for s in self.sentences]).astype(np.int64)
+        self.dev_flat = torch.from_numpy(flat).to(device)
+        self.dev_off = torch.from_numpy(off).to(device)
+        self._pinned = torch.empty((4096,), dtype=torch.int64).pin_memory() if torch.cuda.is_available() else None
+        return self
+
+    def batch_resident(self, idx, truncate=True):
+        """Same tensors as batch(), built from the device-resident CSR arrays (to_device first)."""
+        idx = np.asarray(list(idx), dtype=np.int64)
+        width = int(self.lengths[idx].max()) if truncate else self.max_len
+        if self._pinned is not None and idx.size <= self._pinned.numel():
+            stage = self._pinned[:idx.size]
+            stage.copy_(torch.from_numpy(idx))
+            sel = stage.to(self.dev_flat.device, non_blocking=True)
+        else:
+            sel = torch.from_numpy(idx).to(self.dev_flat.device)
+        return ops.pack_batch_indexed(self.dev_flat, self.dev_off, sel, self.max_len, width, PAD, GO, EOS)
+
     def n_tokens(self, idx):
         """PPL denominator: len + 1 per sentence (Experiment.py:1394)."""
         return int((self.lengths[list(idx)] + 1).sum())
+
+
+def epoch_batches(lengths, batch_size, seed=0, bucket=False, pool=50, drop_last=False):
+    """Index lists of one epoch.  bucket=False: a plain shuffle (DataLoader(shuffle=True),
+    CV/Experiment.py:641).  bucket=True (8f.2): shuffle, cut into pools of pool*batch_size sentences,
+    sort each pool by length, cut into batches, shuffle the batch order -- sentences of similar
+    length share a batch, so the per-batch width (and the recurrence's step count) follows the
+    data instead of the longest outlier.  Changes batch composition, hence opt-in."""
+    rs = np.random.RandomState(seed)
+    n = len(lengths)
+    perm = rs.permutation(n)
+    if bucket:
+        lengths = np.asarray(lengths)
+        step = pool * batch_size
+        perm = np.concatenate([p[np.argsort(-lengths[p], kind='stable')]
+                               for p in (perm[i:i + step] for i in range(0, n, step))])
+    batches = [perm[i:i + batch_size] for i in range(0, n, batch_size)]
+    if drop_last and batches and len(batches[-1]) < batch_size:
+        batches.pop()
+    if bucket:
+        order = rs.permutation(len(batches))
+        batches = [batches[i] for i in order]
+    return [b.tolist() for b in batches]

@@ -39,6 +39,19 @@ def pack_batch(raw_flat, raw_offsets, max_len, width, pad=0, go=1, eos=2):
     return bare, go_t, eos_t, ln
 
 
+def pack_batch_indexed(corpus_flat, corpus_offsets, sel, max_len, width, pad=0, go=1, eos=2):
+    """pack_batch for sentences `sel` (B,) int64 of a device-resident CSR corpus."""
+    B = sel.numel()
+    dev = corpus_flat.device
+    bare = torch.empty((B, width), dtype=torch.int64, device=dev)
+    go_t = torch.empty((B, width + 1), dtype=torch.int64, device=dev)
+    eos_t = torch.empty((B, width + 1), dtype=torch.int64, device=dev)
+    ln = torch.empty((B,), dtype=torch.int64, device=dev)
+    call('cvae_pack_batch_indexed', ptr(corpus_flat), ptr(corpus_offsets), ptr(_c(sel)), B, max_len, width, pad, go,
+         eos, ptr(bare), ptr(go_t), ptr(eos_t), ptr(ln), stream())
+    return bare, go_t, eos_t, ln
+
+
 def sort_resort(length):
     """CV/utils/utils.py:18-21 on device -> (s_idx, res_idx) int64 tensors."""
     length = _c(length)

@@ -35,6 +35,12 @@ int cvae_init(int device);
 int cvae_pack_batch(const int64_t* raw_flat, const int64_t* raw_offsets, int B, int max_len, int width,
                     int64_t pad, int64_t go, int64_t eos, int64_t* bare, int64_t* go_out, int64_t* eos_out,
                     int64_t* len, void* stream);
+/* ---- f2: the same layout for sentences sel[0..B) of a corpus whose CSR arrays are resident on the
+ * device (replaces the reference's DataLoader workers + per-batch host tensors, Experiment.py:641):
+ * per batch only the B indices cross PCIe.  Indices must be within the corpus (not checked). */
+int cvae_pack_batch_indexed(const int64_t* corpus_flat, const int64_t* corpus_offsets, const int64_t* sel, int B,
+                            int max_len, int width, int64_t pad, int64_t go, int64_t eos, int64_t* bare,
+                            int64_t* go_out, int64_t* eos_out, int64_t* len, void* stream);
 /* ---- a2: utils/utils.py:18-21 (sort_resort): stable descending order and its inverse. */
 int cvae_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, void* stream);
 

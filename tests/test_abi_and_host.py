@@ -82,3 +82,20 @@ def test_lambda_kl_matches_reference_formula():
     assert harness.lambda_kl(22000, hp) == 0.5
     assert harness.lambda_kl(2001, hp) == 2.5e-05
     assert harness.lambda_kl(10 ** 7, hp) == 1.0
+
+
+def test_epoch_batches_plain_and_bucketed():
+    """8f.2 host logic: every sentence exactly once per epoch; bucketing groups similar lengths."""
+    import numpy as np
+    from cvae_amd import data
+    s = data.SHAPES['yelp']
+    L = np.array([len(x) for x in data.synthetic_sentences(1000, s['V'], s['mu'], s['sigma'], s['cap'], seed=3)])
+    for bucket in (False, True):
+        bs = data.epoch_batches(L, 32, seed=5, bucket=bucket)
+        assert sorted(i for b in bs for i in b) == list(range(1000))
+        assert bs == data.epoch_batches(L, 32, seed=5, bucket=bucket)           # deterministic
+        assert all(len(b) == 32 for b in bs[:-1]) or bucket
+        assert len(data.epoch_batches(L, 32, seed=5, bucket=bucket, drop_last=True)) == 1000 // 32
+    plain = np.mean([L[b].max() for b in data.epoch_batches(L, 32, seed=5)])
+    buck = np.mean([L[b].max() for b in data.epoch_batches(L, 32, seed=5, bucket=True)])
+    assert buck < 0.6 * plain

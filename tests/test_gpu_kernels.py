@@ -386,3 +386,17 @@ def test_kl_free_bits(dev):
     assert rel(got, ref) < 1e-5
     (got * gk.to(dev)).sum().backward()
     assert rel(md.grad, m64.grad) < 1e-5 and rel(sd.grad, s64.grad) < 1e-5
+
+
+def test_pack_batch_from_resident_corpus(dev):
+    """8f.2: batches gathered from the device-resident CSR corpus by index == the a1 layout built from the
+    batch's own CSR arrays (bit-exact), training (truncated) and evaluation widths, repeated indices."""
+    from cvae_amd import data
+    s = data.SHAPES['ptb']
+    c = data.Corpus(data.synthetic_sentences(300, s['V'], s['mu'], s['sigma'], 40, seed=2), max_len=30).to_device(dev)
+    for idx in ([5, 17, 3, 299, 0, 17], list(range(40, 72)), [123]):
+        for trunc in (True, False):
+            a = c.batch(idx, dev, trunc)
+            b = c.batch_resident(idx, trunc)
+            for x, y in zip(a, b):
+                assert x.dtype == torch.int64 and torch.equal(x, y)
