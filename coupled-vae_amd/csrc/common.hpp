@@ -187,6 +187,11 @@ struct RnnBwd {
 };
 int launch_rnn_backward(const RnnBwd& a, hipStream_t s);
 int launch_rnn_backward_multi(const RnnBwd* a, int ns, hipStream_t s);
+// rnn_large.hip: one step for many rows, gate product + cell in one kernel (IW evaluation)
+bool rnn_large_fused_supported(int cell, int H, const float* h, const float* W_hh);
+int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const float* c_prev, const float* W_hh,
+                          const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
+                          float* c_out, hipStream_t s);
 // rnn_persist.hip: all T steps of up to four lock-stepped sequences in one launch (R <= 32)
 bool rnn_persist_supported(int cell, int T, int R, int H, int ns);
 bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns);

@@ -115,6 +115,11 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
     const int live = a.live_rows ? a.live_rows[k.t] : a.R;
     CVAE_REQUIRE(live >= 0 && live <= a.R, "rnn_forward: live_rows[%d]=%d outside [0,%d]", k.t, live, a.R);
     if (live == 0) continue;
+    if (!a.gates && !a.lengths && rnn_large_fused_supported(a.cell, a.H, k.A, a.W_hh)) {
+      CVAE_TRY(launch_rnn_large_step(a.cell, live, a.H, k.h_prev, k.c_prev, a.W_hh, a.b_hh, k.xproj, a.xmod, xdiv,
+                                     a.xadd, k.h_out, k.c_out, s));
+      continue;
+    }
     const long RH = (long)live * a.H;
     GemmDesc d = {};
     d.transA = 0; d.transB = 1; d.M = live; d.N = G * a.H; d.K = a.H;
