@@ -72,11 +72,12 @@ static int linear_nt(const float* x, const float* W, long ldw, const float* b, i
 }
 
 // dW[N,K] = dy[M,N]^T . x[M,K]
+// db != null: also db[N] = column sums of dy (the bias gradient), see GemmDesc::colsum_out
 static int grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
-                       int beta, hipStream_t s) {
+                       int beta, hipStream_t s, float* db = nullptr) {
   GemmDesc d = {};
   d.transA = 1; d.transB = 0; d.M = N; d.N = K; d.K = M;
-  d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dW; d.ldc = K; d.beta = beta;
+  d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dW; d.ldc = K; d.beta = beta; d.colsum_out = db;
   return launch_gemm(d, s);
 }
 
@@ -258,9 +259,10 @@ int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const
     // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
     const float* hprev = r[d].hs + (d ? BH : 0);
     CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s));
-    CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
-    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s));
-    CVAE_TRY(grad_bias(dgx[d], L * B, G * H, (long)G * H, dw[4 * d + 2], s));
+    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s, dw[4 * d + 2]));
+    // LSTM: both bias vectors see the same pre-activation gradient
+    if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
+    else CVAE_TRY(launch_copy(dw[4 * d + 3], dw[4 * d + 2], (long)G * H, s));
     CVAE_TRY(grad_input(dgx[d], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s));
   }
   CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ids, dX, mask, mask_rows, demb, s));
@@ -514,9 +516,9 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
     const DecBwd& q = dd[d];
     const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
     CVAE_TRY(grad_weight(dgh_eff, GH, q.hs, Hd, T1 * B, (int)GH, Hd, q.dw[1], 0, s));
-    CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, q.dw[3], s));
-    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s));
-    CVAE_TRY(grad_bias(dgx[d], T1 * B, (int)GH, GH, q.dw[2], s));
+    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s, q.dw[2]));
+    if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, q.dw[3], s));
+    else CVAE_TRY(launch_copy(q.dw[3], q.dw[2], GH, s));
     CVAE_TRY(grad_input(dgx[d], GH, q.w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, s));
     CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], q.mask_in, q.dinit, s));
     CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], q.mask_in, nullptr, demb, s));

@@ -89,8 +89,14 @@ struct GemmDesc {
   int beta;                  // 0: overwrite, 1: C += result
   // ACT_CEGRAD epilogue (projce backward): C = coef[m] * (exp(v - lse[m]) - (n == tgt[m]))
   const float* row_lse; const float* row_coef; const int64_t* row_tgt;
+  // transA products only (C = A^T B, weight gradients): also colsum_out[m] = sum_k A[k][m], the bias
+  // gradient.  Free when the product runs as gemm_wide with a spare tile column (a ones column in
+  // the staged B tile); otherwise one extra pass over A.
+  float* colsum_out;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
+int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStream_t s);
+bool gemm_wide_has_spare_column(int N);
 
 // Long-K split-K product with a few hundred output columns (gemm_wide.hip): C += A . B, B = [k][n].
 struct G224Args {

@@ -163,6 +163,18 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
   }
   CVAE_REQUIRE(d.lda >= (d.transA ? d.M : d.K) && d.ldb >= (d.transB ? d.K : d.N) && d.ldc >= d.N,
                "gemm: leading dimension smaller than the row length");
+  if (d.colsum_out) {
+    CVAE_REQUIRE(d.transA && !d.beta, "gemm: colsum_out needs a transA product without accumulation");
+    const bool wide_ok = !d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= 1024 && d.M >= 64 &&
+                         gemm_wide_has_spare_column(d.N);
+    if (!wide_ok) {                       // plain pass over A, then the product without the extra output
+      CVAE_TRY(launch_zero(d.colsum_out, d.M, s));
+      CVAE_TRY(launch_colsum_acc(d.A, d.K, d.M, d.lda, d.colsum_out, s));
+      GemmDesc e = d;
+      e.colsum_out = nullptr;
+      return launch_gemm(e, s);
+    }
+  }
   // Skinny path: few rows, plain A, K long enough to be worth splitting over waves.
   if (!d.transA && d.M <= 64 && d.K >= 64 && d.act != ACT_CEGRAD) {
     SkinnyArgs a = {};
@@ -177,6 +189,7 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
     G224Args w = {};
     w.A = d.A; w.lda = d.lda; w.B = d.B; w.ldb = d.ldb; w.C = d.C; w.ldc = d.ldc;
     w.M = d.M; w.N = d.N; w.K = d.K; w.beta = d.beta;
+    w.extra = d.colsum_out;
     return launch_gemm_wide(!d.transA, w, s);
   }
   const long tiles128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128);

@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
       const bool acc_c = direct && p.beta;
       auto put = [&](int cj, float v) {            // one element: a real column, the ones column, or nothing
         if (cj < ncols) c[cj] = v + (acc_c ? c[cj] : 0.f);
-        else if (cj == ones_col) {
+        else if (cj == ones_col && ntile == 0) {
           if (direct) p.extra[row] = v + (p.beta ? p.extra[row] : 0.f);
-          else c[p.N] = v;                         // slab column N (one n-tile when extra: n0 == 0)
+          else c[p.N] = v;                         // slab column N (n-tile 0: n0 == 0)
         }
       };
       // fragments 0-3: four consecutive columns per lane
@@ -354,16 +354,30 @@ static int lib_part(long floats, float** out) {
   return 0;
 }
 
+// The ones column (bias gradient / row sums as an extra output column) needs the 224-wide tiling
+// with a balanced tile width below 224: true for N <= 220 and for every N whose 224-tiling is the
+// cheaper one anyway.
+static void wide_tiling(int N, bool extra, bool* wide, int* ntiles, int* tile_w) {
+  const int n_eff = N + (extra ? 1 : 0);
+  const int nt7 = cdiv(n_eff, 224), nt4 = cdiv(n_eff, 128);
+  *wide = (7 * nt7 < 4 * nt4) || (extra && N <= 220);
+  *ntiles = *wide ? nt7 : nt4;
+  *tile_w = cdiv(cdiv(N, *ntiles), 4) * 4;
+}
+bool gemm_wide_has_spare_column(int N) {
+  bool wide; int nt, tw;
+  wide_tiling(N, true, &wide, &nt, &tw);
+  return wide && tw <= 220;
+}
+
 int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   CVAE_REQUIRE(a.N > 0, "gemm_wide: N=%d", a.N);
-  CVAE_REQUIRE(a.extra == nullptr || a.N <= 220, "gemm_wide: the ones column needs N <= 220 (N=%d)", a.N);
+  CVAE_REQUIRE(a.extra == nullptr || gemm_wide_has_spare_column(a.N), "gemm_wide: no spare tile column for N=%d", a.N);
   if (a.M <= 0 || a.K <= 0) return 0;
   // balanced n-tiles: 224-wide fragments when that saves MFMA columns, else 128-wide
   const int n_eff = a.N + (a.extra ? 1 : 0);
-  const int nt7 = cdiv(n_eff, 224), nt4 = cdiv(n_eff, 128);
-  const bool wide = (7 * nt7 < 4 * nt4) || a.extra;
-  a.ntiles = wide ? nt7 : nt4;
-  a.tile_w = cdiv(cdiv(a.N, a.ntiles), 4) * 4;
+  bool wide;
+  wide_tiling(a.N, a.extra != nullptr, &wide, &a.ntiles, &a.tile_w);
   a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
   a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
   a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
