@@ -95,12 +95,13 @@ class FlatAdam(object):
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.alias_n = emb.numel() if emb is not None else 0
         off = 0
-        self.views = []
+        self.views, self.gviews = [], []
         for p in uniq:
             k = p.numel()
             self.params[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.params[off:off + k].view_as(p.data)
-            p.grad = self.grads[off:off + k].view_as(p.data)
+            self.gviews.append(self.grads[off:off + k].view_as(p.data))
+            p.grad = self.gviews[-1]
             self.views.append(p)
             off += k
         self.sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -109,10 +110,25 @@ class FlatAdam(object):
         self.lr = hp.lr
 
     def zero_grad(self):
-        self.grads.zero_()
-        for p in self.views:          # keep .grad pointing into the arena
-            if p.grad is None or p.grad.data_ptr() < self.grads.data_ptr():
-                raise RuntimeError('gradient view lost')
+        """Gradients are produced outside the arena and gathered once after backward (gather_grads):
+        with .grad = None autograd hands over each parameter's gradient tensor as it is, instead of
+        adding it into a zeroed arena view with one kernel per parameter (48 per step)."""
+        for p in self.views:
+            p.grad = None
+
+    def gather_grads(self):
+        """One fused copy of every produced gradient into the arena; .grad points into the arena again
+        afterwards.  Segments of parameters without a gradient (None in the reference too) keep the
+        zeros they were created with: nothing ever writes them."""
+        src, dst = [], []
+        for p, g in zip(self.views, self.gviews):
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                src.append(p.grad)
+                dst.append(g)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, g in zip(self.views, self.gviews):
+            p.grad = g
 
     def step(self):
         mult = max(self.n_alias, 1)
@@ -175,6 +191,7 @@ class Trainer(object):
         self.opt.zero_grad()
         res = self.losses(batch)
         res['tot'].backward()
+        self.opt.gather_grads()
         if self.world > 1:
             # the batch mean over equal per-rank batches = mean of per-rank gradients; must
             # complete before the clip (Experiment.py:515 clips the full-batch gradient)
