@@ -207,7 +207,9 @@ def main():
     sents = data.synthetic_sentences(B * n_batches, shape['V'], shape['mu'], shape['sigma'], shape['cap'],
                                      seed=1000 + rank)
     corpus = data.Corpus(sents)
-    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev) for i in range(n_batches)]
+    # rows of a batch in order of non-increasing length (same sentences; the loss is a batch mean): the
+    # backward recurrence then exchanges only the rows still inside their sentence
+    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=True) for i in range(n_batches)]
     tokens = [corpus.n_tokens(range(i * B, (i + 1) * B)) for i in range(n_batches)]
     torch.manual_seed(1234 + rank)                 # dropout / eps streams differ per rank
 
@@ -318,7 +320,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s-shape Coupled-VAE (vae-couple, %s): V=%d E=%d H=%d Z=%d, batch %d per GPU, '
-                                   'lengths lognormal(%.1f,%.2f) cap %d; train step + IW-NLL K=%d'
+                                   'lengths lognormal(%.1f,%.2f) cap %d, rows of a batch ordered by length; train step + IW-NLL K=%d'
                                    % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
                                       shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
                        'parallelism': 'dp%d' % world},

@@ -60,6 +60,7 @@ struct PSeqB {
   float* dgx; float* dgh;            // dgh == dgx for LSTM
   float* dh0; float* dc0;
   int reverse;
+  const int64_t* zero_after;         // [R] or null: row r has an exactly zero gradient at steps t >= zero_after[r]
 };
 struct PBwdArgs {
   PSeqB q[SKINNY_MAX_BATCH];
@@ -362,10 +363,20 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     if (CELL == CELL_LSTM && q.dc_last) dc = q.dc_last[(long)crow * H + cn];
     len = q.lengths ? q.lengths[crow] : (int64_t)T;
   }
+  // Rows whose gradient is exactly zero at step t (a padded step of a packed sequence; a decoder row
+  // past its last target) produce an all-zero partial row: such rows are neither published nor
+  // gathered.  bound(t) = 1 + the highest row that is still non-zero at step t; with the batch's rows
+  // ordered by length that is the live-row count, and the exchange traffic follows it.
+  const int64_t za = (lane < R) ? (q.zero_after ? q.zero_after[lane] : (q.lengths ? q.lengths[lane] : (int64_t)T)) : 0;
+  auto row_bound = [&](int t) -> int {
+    const unsigned long long m = __ballot(lane < 32 && (int64_t)t < za);
+    return m ? 64 - __clzll(m) : 0;
+  };
+  int rb_prev = 0;                                      // bound of the partials published last
   __syncthreads();
 
   // sum over all source blocks of their partial for (crow, cu); parity = buffer to read
-  auto gather = [&](int parity) -> float {
+  auto gather = [&](int parity, int bound) -> float {
     const long base = (long)parity * ex_par + (long)blockIdx.x * nb * 128;
     // piece p = src * 32 + row; this thread takes p = tid, tid + 1024, ...
     f32x4v sum = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     for (int j = 0; j < 4; ++j) {
       v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
       const int pc = tid + P_THREADS * j;
-      if (pc < npieces) v[j] = ld16_sc1(rs_ex, base + (long)pc * 4);
+      if (pc < npieces && (tid & 31) < bound) v[j] = ld16_sc1(rs_ex, base + (long)pc * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sum += v[j];
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     if (i < T - 1) {
       if (!wait_flags(flg, nb, (unsigned)(T - 1 - i), p.status, &s_abort)) return;
       P_STAMP(1);
-      part = gather((T - 1 - i) & 1);
+      part = gather((T - 1 - i) & 1, rb_prev);
       P_STAMP(2);
     }
     if (cellt) {
@@ -476,10 +487,11 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     {
       const long wbase = (long)((T - i) & 1) * ex_par + (long)blockIdx.x * 128;
       const int npieces = nb * 32;
+      rb_prev = row_bound(t);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pc = tid + P_THREADS * j;
-        if (pc < npieces) {
+        if (pc < npieces && (pc & 31) < rb_prev) {
           const int d = pc >> 5, r = pc & 31;
           const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + r * LDT + 4 * d);
           st16_sc1(rs_ex, wbase + ((long)d * nb) * 128 + (long)r * 4, v);
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   float part = 0.f;
   if (T > 0) {
     if (!wait_flags(flg, nb, (unsigned)T, p.status, &s_abort)) return;
-    part = gather(T & 1);
+    part = gather(T & 1, rb_prev);
   }
   if (crv) {
     q.dh0[(long)crow * H + cn] = dh_carry + part;
@@ -507,11 +519,12 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
 // ------------------------------------------------------------------------------------ host side
 // library-owned sync words: [SKINNY_MAX_BATCH][P_MAXB] epoch flags | 16 status words | 16 stamp accumulators
 constexpr int P_FLAG_WORDS = SKINNY_MAX_BATCH * P_MAXB;
+constexpr size_t P_ZA_OFFSET = (size_t)(P_FLAG_WORDS + 16) * 4 + 16 * 8;      // int64 [SKINNY_MAX_BATCH][32] after the stamps
 static unsigned* g_sync = nullptr;
 static int g_stamps_on = -1;
 static int persist_sync(unsigned** out) {
   if (!g_sync) {
-    const size_t bytes = (size_t)(P_FLAG_WORDS + 16) * 4 + 16 * 8;
+    const size_t bytes = P_ZA_OFFSET + (size_t)SKINNY_MAX_BATCH * 32 * 8;
     CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_sync), bytes), "persist sync words"));
     CVAE_TRY(check_hip(hipMemset(g_sync, 0, bytes), "persist sync memset"));
     const char* e = getenv("CVAE_PERSIST_STAMPS");
@@ -594,6 +607,31 @@ static int persist_exch(long floats, float** out) {
   return 0;
 }
 
+// out[r] = max(out[r], 1 + the last step t with a non-zero entry in dhs[t, r, :]); out zeroed before.
+// grid (R, time chunks): each block scans its steps of one row.
+__global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, int H, int tchunk,
+                                                                const float* __restrict__ dhs,
+                                                                unsigned long long* __restrict__ out) {
+  __shared__ int smax[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+  int best = 0;
+  for (int t = t0; t < t1; ++t) {
+    const float* row = dhs + ((long)t * R + r) * H;
+    bool nz = false;
+    for (int h = tid; h < H; h += 256) nz |= (row[h] != 0.f);
+    if (nz) best = t + 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off, 64));
+  if ((tid & 63) == 0) smax[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    const int m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (m > 0) atomicMax(out + r, (unsigned long long)m);
+  }
+}
+
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   unsigned* sync = nullptr;
   CVAE_TRY(persist_sync(&sync));
@@ -610,7 +648,18 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
     float* dgh = r.dgh ? r.dgh : r.dgx;
     CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0,
                  "rnn_backward_persist: operands must be 16-byte aligned");
-    p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse};
+    // unpacked sequences (decoders): rows past their last non-zero output gradient stay exactly zero
+    const int64_t* za = nullptr;
+    if (!r.lengths && r.dhs && !r.dh_last && !r.dc_last && p.R <= 32) {
+      int64_t* zbuf = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(sync) + P_ZA_OFFSET) + (size_t)k * 32;
+      CVAE_TRY(launch_zero(reinterpret_cast<float*>(zbuf), 64, s));
+      const int tchunk = cdiv(p.T, 32);
+      hipLaunchKernelGGL(last_nonzero_step_kernel, dim3(p.R, cdiv(p.T, tchunk)), dim3(256), 0, s, p.T, p.R, p.H, tchunk,
+                         r.dhs, reinterpret_cast<unsigned long long*>(zbuf));
+      CVAE_LAUNCH_CHECK("last_nonzero_step_kernel");
+      za = zbuf;
+    }
+    p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse, za};
   }
   long lds_floats = 32L * (p.H + 4);
   if (lds_floats < 4096) lds_floats = 4096;

@@ -38,9 +38,15 @@ class Corpus(object):
     def __len__(self):
         return len(self.sentences)
 
-    def batch(self, idx, device, truncate=True):
+    def batch(self, idx, device, truncate=True, sort_rows=False):
         """-> bare (B,L), go (B,L+1), eos (B,L+1), len (B,) int64 on `device`.
-        truncate=True: training layout (cut to the batch maximum, Experiment.py:659-664)."""
+        truncate=True: training layout (cut to the batch maximum, Experiment.py:659-664).
+        sort_rows=True: the batch's rows in order of non-increasing length (same sentences; the
+        loss is a batch mean, so the order is free) -- the backward recurrence then exchanges only the
+        rows that are still inside their sentence."""
+        idx = list(idx)
+        if sort_rows:
+            idx = sorted(idx, key=lambda i: -int(self.lengths[i]))
         sents = [self.sentences[i] for i in idx]
         flat = np.concatenate(sents) if sents else np.zeros((0,), np.int64)
         off = np.cumsum([0] + [len(s) for s in sents]).astype(np.int64)

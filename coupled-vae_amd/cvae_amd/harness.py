@@ -249,8 +249,8 @@ class Trainer(object):
         return a[0] / max(a[1], 1.0)
 
 
-def text_batch(corpus, idx, device, truncate=True):
-    bare, go, eos, ln = corpus.batch(idx, device, truncate)
+def text_batch(corpus, idx, device, truncate=True, sort_rows=False):
+    bare, go, eos, ln = corpus.batch(idx, device, truncate, sort_rows)
     return dict(bare=bare, go=go, eos=eos, len=ln)
 
 

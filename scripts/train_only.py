@@ -12,7 +12,8 @@ hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], 
 tr = harness.Trainer(hp, dev, seed=0)
 B = 32
 corpus = data.Corpus(data.synthetic_sentences(B * 8, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
-batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev) for i in range(8)]
+sort_rows = os.environ.get('SORT_ROWS', '1') == '1'
+batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=sort_rows) for i in range(8)]
 for i in range(5):
     tr.train_step(batches[i % 8])
 torch.cuda.synchronize(); t0 = time.perf_counter()
