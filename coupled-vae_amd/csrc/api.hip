@@ -72,21 +72,49 @@ static int linear_nt(const float* x, const float* W, long ldw, const float* b, i
 }
 
 // dW[N,K] = dy[M,N]^T . x[M,K]
+// Time-major live-row list of a [T, B, .] gradient (device): rows whose gradient is exactly zero (padded
+// steps, decoder rows past their last target) are left out of the products that consume it.
+struct LiveRows { const int* rows; const int* n; };
+
+static bool live_rows_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CVAE_LIVE_ROWS"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+// library-owned index scratch (grown on demand; launches that use it must be on one stream)
+static int* g_rows = nullptr;
+static long g_rows_ints = 0;
+static int lib_rows(long ints, int** out) {
+  if (ints > g_rows_ints) {
+    if (g_rows) CVAE_TRY(check_hip(hipFree(g_rows), "live-row scratch free"));          // implicit device sync
+    g_rows = nullptr; g_rows_ints = 0;
+    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_rows), (size_t)ints * sizeof(int)), "live-row scratch"));
+    g_rows_ints = ints;
+  }
+  *out = g_rows;
+  return 0;
+}
+
 // db != null: also db[N] = column sums of dy (the bias gradient), see GemmDesc::colsum_out
+// lr != null: only the listed rows of dy / x are visited (the others are exactly zero in dy)
 static int grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
-                       int beta, hipStream_t s, float* db = nullptr) {
+                       int beta, hipStream_t s, float* db = nullptr, const LiveRows* lr = nullptr) {
   GemmDesc d = {};
   d.transA = 1; d.transB = 0; d.M = N; d.N = K; d.K = M;
   d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dW; d.ldc = K; d.beta = beta; d.colsum_out = db;
+  if (lr) { d.rows = lr->rows; d.nlive = lr->n; d.bound_dim = 2; }
   return launch_gemm(d, s);
 }
 
 // dx[M,K] = dy[M,N] . W[N,K]
+// lr != null: only the listed rows of dy are visited and only those rows of dx written: the caller has
+// zeroed dx (beta == 0) or dx already holds the term to add to (beta == 1)
 static int grad_input(const float* dy, long lddy, const float* W, long ldw, int M, int N, int K, float* dx,
-                      long lddx, int beta, hipStream_t s) {
+                      long lddx, int beta, hipStream_t s, const LiveRows* lr = nullptr) {
   GemmDesc d = {};
   d.transA = 0; d.transB = 0; d.M = M; d.N = K; d.K = N;
   d.A = dy; d.lda = lddy; d.B = W; d.ldb = ldw; d.C = dx; d.ldc = lddx; d.beta = beta;
+  if (lr) { d.rows = lr->rows; d.nlive = lr->n; d.bound_dim = 1; }
   return launch_gemm(d, s);
 }
 
@@ -253,17 +281,28 @@ int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const
     r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
   }
   CVAE_TRY(launch_rnn_backward_multi(r, 2, s));
+  // padded steps (t >= len[b]) have exactly zero pre-activation gradients: leave them out
+  LiveRows live = {nullptr, nullptr};
+  const LiveRows* lr = nullptr;
+  if (live_rows_enabled() && (long)L * B >= 1024) {
+    int* buf = nullptr;
+    CVAE_TRY(lib_rows(16 + (long)L * B, &buf));
+    CVAE_TRY(launch_live_rows_tm(L, B, len, 0, buf + 16, buf, s));
+    live.rows = buf + 16; live.n = buf;
+    lr = &live;
+    CVAE_TRY(launch_zero(dX, (long)L * B * E, s));
+  }
   for (int d = 0; d < 2; ++d) {
     const float* W_ih = w[4 * d + 0];
     const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
     // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
     const float* hprev = r[d].hs + (d ? BH : 0);
-    CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s));
-    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s, dw[4 * d + 2]));
+    CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s, nullptr, lr));
+    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s, dw[4 * d + 2], lr));
     // LSTM: both bias vectors see the same pre-activation gradient
     if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
     else CVAE_TRY(launch_copy(dw[4 * d + 3], dw[4 * d + 2], (long)G * H, s));
-    CVAE_TRY(grad_input(dgx[d], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s));
+    CVAE_TRY(grad_input(dgx[d], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s, lr));
   }
   CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ids, dX, mask, mask_rows, demb, s));
   return 0;
@@ -485,6 +524,14 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   const long BH = (long)B * Hd, GH = (long)G * Hd;
   RnnBwd r[SKINNY_MAX_BATCH] = {};
   float* dgx[SKINNY_MAX_BATCH]; float* dgh[SKINNY_MAX_BATCH]; float* dX[SKINNY_MAX_BATCH];
+  LiveRows live_w[SKINNY_MAX_BATCH], live_r[SKINNY_MAX_BATCH];
+  const LiveRows* lrw[SKINNY_MAX_BATCH]; const LiveRows* lrr[SKINNY_MAX_BATCH];
+  const bool use_live = live_rows_enabled() && (long)T * B >= 1024 && B <= 32;
+  const long per_dec = (4L * B + 16 + (long)T * B + (long)T1 * B + 3) / 4 * 4;     // ints per decoder
+  int* rows_buf = nullptr;
+  if (use_live) {
+    CVAE_TRY(lib_rows((long)nd * per_dec, &rows_buf));   // shared with the encoder's list: calls are stream-ordered
+  }
   for (int d = 0; d < nd; ++d) {
     const DecBwd& q = dd[d];
     CVAE_REQUIRE(q.w && q.X && q.hs && q.gates && q.final && q.dfinal && q.dinit && q.dw && q.scratch,
@@ -499,12 +546,29 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
     float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
     float* whhT = dc_tmp + BH;
     const float* hout = q.mask_out ? q.hdrop : q.hs + 2 * BH;
+    // Rows (t, b) past sentence b's last target receive an exactly zero dfinal row (the loss ignores
+    // <pad>): find each sentence's last non-zero step and leave the dead rows out of every product.
+    lrw[d] = lrr[d] = nullptr;
+    if (use_live) {
+      int* buf = rows_buf + (long)d * per_dec;
+      int64_t* za = reinterpret_cast<int64_t*>(buf);            // [B] last live target step + 1
+      int64_t* za1 = za + B;                                    // [B] the same in recurrence steps (prefix step first)
+      int* cnt = buf + 4 * B;
+      CVAE_TRY(launch_last_nonzero_step(T, B, E, q.dfinal, za, s));
+      CVAE_TRY(launch_add_i64(za, 1, B, za1, s));
+      CVAE_TRY(launch_live_rows_tm(T, B, za, 0, cnt + 16, cnt, s));
+      CVAE_TRY(launch_live_rows_tm(T1, B, za1, 0, cnt + 16 + (long)T * B, cnt + 1, s));
+      live_w[d].rows = cnt + 16; live_w[d].n = cnt;
+      live_r[d].rows = cnt + 16 + (long)T * B; live_r[d].n = cnt + 1;
+      lrw[d] = &live_w[d]; lrr[d] = &live_r[d];
+      r[d].zero_after = za1;
+    }
     // final = tanh(hout W_c^T + b_c)
     CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre, s));
-    CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, q.dw[4], 0, s));
+    CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, q.dw[4], 0, s, nullptr, lrw[d]));
     CVAE_TRY(grad_bias(dpre, T * B, E, E, q.dw[5], s));
-    CVAE_TRY(launch_zero(dhs, (long)BH, s));
-    CVAE_TRY(grad_input(dpre, E, q.w[4], Hd, T * B, E, Hd, dhs + BH, Hd, 0, s));
+    CVAE_TRY(launch_zero(dhs, use_live ? (long)T1 * BH : (long)BH, s));
+    CVAE_TRY(grad_input(dpre, E, q.w[4], Hd, T * B, E, Hd, dhs + BH, Hd, 0, s, lrw[d]));
     if (q.mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, q.mask_out, dhs + BH, s));
     r[d].cell = cell; r[d].T = T1; r[d].R = B; r[d].H = Hd; r[d].reverse = 0;
     r[d].dhs = dhs; r[d].hs = q.hs; r[d].cs = q.cs; r[d].gates = q.gates; r[d].W_hh = q.w[1];
@@ -515,11 +579,12 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   for (int d = 0; d < nd; ++d) {
     const DecBwd& q = dd[d];
     const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
-    CVAE_TRY(grad_weight(dgh_eff, GH, q.hs, Hd, T1 * B, (int)GH, Hd, q.dw[1], 0, s));
-    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s, q.dw[2]));
+    CVAE_TRY(grad_weight(dgh_eff, GH, q.hs, Hd, T1 * B, (int)GH, Hd, q.dw[1], 0, s, nullptr, lrr[d]));
+    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s, q.dw[2], lrr[d]));
     if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, q.dw[3], s));
     else CVAE_TRY(launch_copy(q.dw[3], q.dw[2], GH, s));
-    CVAE_TRY(grad_input(dgx[d], GH, q.w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, s));
+    if (lrr[d]) CVAE_TRY(launch_zero(dX[d], (long)T1 * B * 2 * E, s));
+    CVAE_TRY(grad_input(dgx[d], GH, q.w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, s, lrr[d]));
     CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], q.mask_in, q.dinit, s));
     CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], q.mask_in, nullptr, demb, s));
   }

@@ -93,6 +93,11 @@ struct GemmDesc {
   // gradient.  Free when the product runs as gemm_wide with a spare tile column (a ones column in
   // the staged B tile); otherwise one extra pass over A.
   float* colsum_out;
+  // Optional live-row list (device): the product only visits rows[0 .. *nlive) of the row dimension
+  // that A shares with C (bound_dim 1: C = A B, rows of A and C; the caller has zeroed C) or with
+  // B (bound_dim 2, transA: C = A^T B, rows of A and B).  Rows outside the list must be exactly
+  // zero in A for the result to be the full product.  Always runs as gemm_wide.
+  const int* rows; const int* nlive; int bound_dim;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
 int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStream_t s);
@@ -107,6 +112,7 @@ struct G224Args {
   const int* nlive; int r0;   // optional device-side bound: lim = max(0, *nlive - r0)
   int dev_bound;              // 0: none; 1: M <= lim, C row = rows[r0 + m]; 2: K <= lim, B row = rows[r0 + k]
   const int* rows;
+  int a_ind;                  // 1: rows of A are gathered through rows[] too (A[rows[r0+m]][k] / A[rows[r0+k]][m])
   float* extra;               // optional [M]: extra[m] (+)= sum_k A[m,k] (a ones column appended to B; N <= 220)
   int beta;                   // 0: C (and extra) overwritten, 1: accumulated into
   float* part;                // partial-sum slabs (gemm_wide_part_floats); null -> library scratch
@@ -186,6 +192,7 @@ struct RnnBwd {
   const float* hs; const float* cs; const float* gates;
   const float* W_hh;
   const int64_t* lengths;
+  const int64_t* zero_after;        // [R] or null: row r's incoming gradient is exactly zero at steps t >= zero_after[r]
   float* dgx; float* dgh;           // [T,R,G*H] pre-activation grads, x side / h side (LSTM: dgh may be null = dgx)
   float* dh0; float* dc0;           // [R,H] out: grad wrt the initial state
   float* whhT;                      // [H, G*H] scratch: W_hh transposed (needed when R <= SKINNY_MAX_ROWS)

@@ -175,6 +175,24 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
       return launch_gemm(e, s);
     }
   }
+  if (d.rows) {
+    CVAE_REQUIRE(d.nlive && !d.transB && d.act == ACT_NONE && !d.bias &&
+                 ((d.bound_dim == 1 && !d.transA) || (d.bound_dim == 2 && d.transA)),
+                 "gemm: live-row list with an unsupported product form");
+    G224Args w = {};
+    w.A = d.A; w.lda = d.lda; w.B = d.B; w.ldb = d.ldb; w.C = d.C; w.ldc = d.ldc;
+    w.M = d.M; w.N = d.N; w.K = d.K; w.beta = d.beta;
+    w.rows = d.rows; w.nlive = d.nlive; w.r0 = 0; w.dev_bound = d.bound_dim; w.a_ind = 1;
+    if (d.colsum_out) {
+      if (gemm_wide_has_spare_column(d.N)) {
+        w.extra = d.colsum_out;
+      } else {
+        CVAE_TRY(launch_zero(d.colsum_out, d.M, s));
+        CVAE_TRY(launch_colsum_acc(d.A, d.K, d.M, d.lda, d.colsum_out, s));
+      }
+    }
+    return launch_gemm_wide(!d.transA, w, s);
+  }
   // Skinny path: few rows, plain A, K long enough to be worth splitting over waves.
   if (!d.transA && d.M <= 64 && d.K >= 64 && d.act != ACT_CEGRAD) {
     SkinnyArgs a = {};

@@ -126,11 +126,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
     const float* pa[2];
     const float* pb[4];
     int brn[4];                                // dev_bound == 2: B row index of the next interior chunk
+    int arn[2];                                // a_ind, k-major A: A row index of the next interior chunk
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i;
-      if (AKC) pa[i] = p.A + (long)min(m0 + (idx >> 2), Mlim - 1) * p.lda + kbeg + 4 * (idx & 3);
-      else pa[i] = p.A + (long)(kbeg + (idx >> 5)) * p.lda + m0 + 4 * (idx & 31);
+      arn[i] = 0;
+      if (AKC) {
+        const int mm = min(m0 + (idx >> 2), Mlim - 1);
+        const long arow = p.a_ind ? (long)p.rows[p.r0 + mm] : (long)mm;
+        pa[i] = p.A + arow * p.lda + kbeg + 4 * (idx & 3);
+      } else if (p.a_ind) {
+        pa[i] = p.A + m0 + 4 * (idx & 31);
+        arn[i] = p.rows[p.r0 + min(kbeg + (idx >> 5), Klim - 1)];
+      } else {
+        pa[i] = p.A + (long)(kbeg + (idx >> 5)) * p.lda + m0 + 4 * (idx & 31);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -143,8 +153,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
     int knext = kbeg + G2_BK;                  // first k of the chunk after the one being loaded
     // loads the next interior chunk of this item (chunks are taken in order)
     auto fast_load = [&]() {
+      if (!AKC && p.a_ind) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { sa[i] = *reinterpret_cast<const float4*>(pa[i]); pa[i] += a_step; }
+        for (int i = 0; i < 2; ++i) sa[i] = *reinterpret_cast<const float4*>(pa[i] + (long)arn[i] * p.lda);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) arn[i] = p.rows[p.r0 + min(knext + ((tid + 256 * i) >> 5), Klim - 1)];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { sa[i] = *reinterpret_cast<const float4*>(pa[i]); pa[i] += a_step; }
+      }
       if (p.dev_bound == 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -165,10 +182,16 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (AKC) {
           const int row = m0 + (idx >> 2), k = k0 + 4 * (idx & 3);
-          if (row < Mlim && k < kend) v = ld4g(p.A + (long)row * p.lda + k, k, kend, p.vecA);
+          if (row < Mlim && k < kend) {
+            const long arow = p.a_ind ? (long)p.rows[p.r0 + row] : (long)row;
+            v = ld4g(p.A + arow * p.lda + k, k, kend, p.vecA);
+          }
         } else {
           const int k = k0 + (idx >> 5), m = m0 + 4 * (idx & 31);
-          if (k < kend && m < Mlim) v = ld4g(p.A + (long)k * p.lda + m, m, Mlim, p.vecA);
+          if (k < kend && m < Mlim) {
+            const long arow = p.a_ind ? (long)p.rows[p.r0 + k] : (long)k;
+            v = ld4g(p.A + arow * p.lda + m, m, Mlim, p.vecA);
+          }
         }
         sa[i] = v;
       }
@@ -373,6 +396,8 @@ bool gemm_wide_has_spare_column(int N) {
 int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   CVAE_REQUIRE(a.N > 0, "gemm_wide: N=%d", a.N);
   CVAE_REQUIRE(a.extra == nullptr || gemm_wide_has_spare_column(a.N), "gemm_wide: no spare tile column for N=%d", a.N);
+  CVAE_REQUIRE(!a.a_ind || (a.rows && ((akc && a.dev_bound == 1) || (!akc && a.dev_bound == 2))),
+               "gemm_wide: A-row indirection needs the row list and the matching device bound");
   if (a.M <= 0 || a.K <= 0) return 0;
   // balanced n-tiles: 224-wide fragments when that saves MFMA columns, else 128-wide
   const int n_eff = a.N + (a.extra ? 1 : 0);

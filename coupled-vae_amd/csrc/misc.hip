@@ -357,6 +357,91 @@ int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, 
   return 0;
 }
 
+// Time-major list of the (t, b) pairs with t < za[b] + off, as row ids k = t*B + b in ascending order,
+// and its length.  One block; T is walked in slabs of 256 steps with an LDS scan of the per-step counts.
+__global__ __launch_bounds__(256) void live_rows_tm_kernel(int T, int B, const int64_t* __restrict__ za, int off,
+                                                           int* __restrict__ rows, int* __restrict__ count) {
+  __shared__ int sc[256];
+  __shared__ int base;
+  const int tid = threadIdx.x;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    int n = 0;
+    if (t < T)
+      for (int b = 0; b < B; ++b) n += ((int64_t)t < za[b] + off) ? 1 : 0;
+    sc[tid] = n;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int v = (tid >= d) ? sc[tid - d] : 0;
+      __syncthreads();
+      sc[tid] += v;
+      __syncthreads();
+    }
+    int o = base + sc[tid] - n;
+    if (t < T)
+      for (int b = 0; b < B; ++b)
+        if ((int64_t)t < za[b] + off) rows[o++] = t * B + b;
+    __syncthreads();
+    if (tid == 255) base += sc[255];
+    __syncthreads();
+  }
+  if (tid == 0) *count = base;
+}
+int launch_live_rows_tm(int T, int B, const int64_t* za, int off, int* rows, int* count, hipStream_t s) {
+  CVAE_REQUIRE(T >= 0 && B > 0 && za && rows && count, "live_rows_tm: bad arguments");
+  hipLaunchKernelGGL(live_rows_tm_kernel, dim3(1), dim3(256), 0, s, T, B, za, off, rows, count);
+  CVAE_LAUNCH_CHECK("live_rows_tm_kernel");
+  return 0;
+}
+
+__global__ void add_i64_kernel(const int64_t* __restrict__ x, int64_t c, int n, int64_t* __restrict__ y) {
+  IDX1D(n);
+  y[idx] = x[idx] + c;
+}
+int launch_add_i64(const int64_t* x, int64_t c, int n, int64_t* y, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_i64_kernel, GRID1D(n), 0, s, x, c, n, y);
+  CVAE_LAUNCH_CHECK("add_i64_kernel");
+  return 0;
+}
+
+// za[r] = max(za[r], 1 + the last step t with a non-zero entry in x[t, r, :]); za zeroed by the caller.
+// grid (R, time chunks).
+__global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, int H, int tchunk,
+                                                                const float* __restrict__ x,
+                                                                unsigned long long* __restrict__ za) {
+  __shared__ int smax[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+  int best = 0;
+  for (int t = t0; t < t1; ++t) {
+    const float* row = x + ((long)t * R + r) * H;
+    bool nz = false;
+    for (int h = tid; h < H; h += 256) nz |= (row[h] != 0.f);
+    if (nz) best = t + 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off, 64));
+  if ((tid & 63) == 0) smax[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    const int m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (m > 0) atomicMax(za + r, (unsigned long long)m);
+  }
+}
+// za (int64 [R]) is zeroed here
+int launch_last_nonzero_step(int T, int R, int H, const float* x, int64_t* za, hipStream_t s) {
+  CVAE_REQUIRE(T > 0 && R > 0 && H > 0 && x && za, "last_nonzero_step: bad arguments");
+  CVAE_TRY(launch_zero(reinterpret_cast<float*>(za), 2L * R, s));
+  const int tchunk = cdiv(T, 32);
+  hipLaunchKernelGGL(last_nonzero_step_kernel, dim3(R, cdiv(T, tchunk)), dim3(256), 0, s, T, R, H, tchunk, x,
+                     reinterpret_cast<unsigned long long*>(za));
+  CVAE_LAUNCH_CHECK("last_nonzero_step_kernel");
+  return 0;
+}
+
 // logits[b, t, v] = tmp[t*B + b, v]
 __global__ void logits_bt_kernel(int T, int B, long V, const float* __restrict__ tmp, float* __restrict__ out) {
   IDX1D((long)T * B * V);

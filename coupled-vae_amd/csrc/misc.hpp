@@ -24,6 +24,9 @@ int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hip
 int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s);
 int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, int64_t* out, long out_ld,
                        long out_off, int64_t* cur, hipStream_t s);
+int launch_add_i64(const int64_t* x, int64_t c, int n, int64_t* y, hipStream_t s);
+int launch_live_rows_tm(int T, int B, const int64_t* za, int off, int* rows, int* count, hipStream_t s);
+int launch_last_nonzero_step(int T, int R, int H, const float* x, int64_t* za, hipStream_t s);
 int launch_logits_bt(int T, int B, long V, const float* tmp, float* out, hipStream_t s);
 int launch_reparam_fwd(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,
                        hipStream_t s);

@@ -28,6 +28,7 @@
 //     Every spin is bounded: on a timeout the block raises the status word and the
 //     whole grid drains (cvae_persist_status reports it).
 #include "common.hpp"
+#include "misc.hpp"
 #include "cell_math.hpp"
 
 namespace cvae {
@@ -607,31 +608,6 @@ static int persist_exch(long floats, float** out) {
   return 0;
 }
 
-// out[r] = max(out[r], 1 + the last step t with a non-zero entry in dhs[t, r, :]); out zeroed before.
-// grid (R, time chunks): each block scans its steps of one row.
-__global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, int H, int tchunk,
-                                                                const float* __restrict__ dhs,
-                                                                unsigned long long* __restrict__ out) {
-  __shared__ int smax[4];
-  const int r = blockIdx.x, tid = threadIdx.x;
-  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
-  int best = 0;
-  for (int t = t0; t < t1; ++t) {
-    const float* row = dhs + ((long)t * R + r) * H;
-    bool nz = false;
-    for (int h = tid; h < H; h += 256) nz |= (row[h] != 0.f);
-    if (nz) best = t + 1;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off, 64));
-  if ((tid & 63) == 0) smax[tid >> 6] = best;
-  __syncthreads();
-  if (tid == 0) {
-    const int m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-    if (m > 0) atomicMax(out + r, (unsigned long long)m);
-  }
-}
-
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   unsigned* sync = nullptr;
   CVAE_TRY(persist_sync(&sync));
@@ -649,14 +625,10 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
     CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0,
                  "rnn_backward_persist: operands must be 16-byte aligned");
     // unpacked sequences (decoders): rows past their last non-zero output gradient stay exactly zero
-    const int64_t* za = nullptr;
-    if (!r.lengths && r.dhs && !r.dh_last && !r.dc_last && p.R <= 32) {
+    const int64_t* za = r.zero_after;
+    if (!za && !r.lengths && r.dhs && !r.dh_last && !r.dc_last && p.R <= 32) {
       int64_t* zbuf = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(sync) + P_ZA_OFFSET) + (size_t)k * 32;
-      CVAE_TRY(launch_zero(reinterpret_cast<float*>(zbuf), 64, s));
-      const int tchunk = cdiv(p.T, 32);
-      hipLaunchKernelGGL(last_nonzero_step_kernel, dim3(p.R, cdiv(p.T, tchunk)), dim3(256), 0, s, p.T, p.R, p.H, tchunk,
-                         r.dhs, reinterpret_cast<unsigned long long*>(zbuf));
-      CVAE_LAUNCH_CHECK("last_nonzero_step_kernel");
+      CVAE_TRY(launch_last_nonzero_step(p.T, p.R, p.H, r.dhs, zbuf, s));
       za = zbuf;
     }
     p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse, za};
