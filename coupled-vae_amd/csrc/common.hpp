@@ -117,7 +117,7 @@ struct G224Args {
   int beta;                   // 0: C (and extra) overwritten, 1: accumulated into
   float* part;                // partial-sum slabs (gemm_wide_part_floats); null -> library scratch
   long prof_units;            // profiling: live extent of the device-bounded dimension (0: use the host bound)
-  int ntiles, tile_w, part_ld;   // filled by the launcher
+  int ntiles, tile_w, part_ld, min_chunks;   // filled by the launcher
   int vecA, vecB, vecC;
 };
 long gemm_wide_part_floats(int N, bool extra);

@@ -73,7 +73,7 @@ __device__ __forceinline__ WideLayout wide_layout(const G224Args& p, int nblk) {
   w.mt = (w.Mlim + G2_BM - 1) / G2_BM;
   const int kunits = (w.Klim + G2_BK - 1) / G2_BK;
   int ks = (w.mt > 0) ? nblk / (w.mt * p.ntiles) : 1;
-  if (ks > kunits / 4) ks = kunits / 4;      // at least 4 chunks per item
+  if (ks > kunits / p.min_chunks) ks = kunits / p.min_chunks;      // at least min_chunks chunks per item
   if (ks < 1) ks = 1;
   w.kchunk = ((kunits + ks - 1) / ks) * G2_BK;
   w.ks = (w.kchunk > 0) ? (w.Klim + w.kchunk - 1) / w.kchunk : 1;
@@ -407,6 +407,11 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
   a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
   a.part_ld = (n_eff + 3) / 4 * 4;
+  {
+    static int mc = 0;
+    if (!mc) { const char* e = getenv("CVAE_WIDE_MIN_CHUNKS"); mc = e ? atoi(e) : 4; if (mc < 1 || mc > 256) mc = 4; }
+    a.min_chunks = mc;
+  }
   if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part));
   const int nblk = wide_grid_blocks();
   const dim3 grid(nblk), block(256);

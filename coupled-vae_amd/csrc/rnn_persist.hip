@@ -566,7 +566,11 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s) {
   PFwdArgs p = {};
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
   p.nw = 0;
-  for (int nw = 16; nw >= 2 && !p.nw; nw >>= 1)                        // K per wave: multiple of 16, <= 64
+  static int nw_max = 0;
+  if (!nw_max) { const char* e = getenv("CVAE_PERSIST_NW"); nw_max = e ? atoi(e) : 16; if (nw_max < 2 || nw_max > 16) nw_max = 16; }
+  for (int nw = nw_max; nw >= 2 && !p.nw; nw >>= 1)                    // K per wave: multiple of 16, <= 64
+    if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
+  for (int nw = 16; nw >= 2 && !p.nw; nw >>= 1)
     if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
   CVAE_REQUIRE(p.nw >= 1 && p.nw <= 16 && p.H % p.nw == 0 && (p.H / p.nw) % 16 == 0 && p.H / p.nw <= 64,
                "rnn_forward_persist: H=%d does not split over the block's waves", p.H);

@@ -34,6 +34,12 @@ def bench_gemm():
         ('xproj     NT  6400x1024x200', 6400, 1024, 200, 0, 1),
         ('dWih      TN  1024x200x6400', 1024, 200, 6400, 1, 0),
         ('dxin      NN  6400x200x1024', 6400, 200, 1024, 0, 0),
+        ('dec dWih  TN  2048x400x6400', 2048, 400, 6400, 1, 0),
+        ('dec dWih  TN  2048x400x3000', 2048, 400, 3000, 1, 0),
+        ('dec dWhh  TN  2048x512x6400', 2048, 512, 6400, 1, 0),
+        ('dec dX    NN  6400x400x2048', 6400, 400, 2048, 0, 0),
+        ('dec dX    NN  3000x400x2048', 3000, 400, 2048, 0, 0),
+        ('dec xproj NT  6400x2048x400', 6400, 2048, 400, 0, 1),
         ('eval hWhh NT 16000x1024x256', 16000, 1024, 256, 0, 1),
         ('eval hWhh NT 16000x768x256', 16000, 768, 256, 0, 1),
         ('eval Wc   NT 16000x200x256', 16000, 200, 256, 0, 1),
