@@ -151,7 +151,11 @@ int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
     for (int q = 0; q < ns; ++q) CVAE_TRY(rnn_forward_large(a[q], s));
     return 0;
   }
-  if (rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns)) return launch_rnn_forward_persist(a, ns, s);
+  bool aligned = true;                    // the whole-sequence kernel reads and writes with 16-byte accesses
+  for (int q = 0; q < ns; ++q)
+    aligned = aligned && aligned16(a[q].hs) && (!a[q].cs || aligned16(a[q].cs)) &&
+              (!a[q].gates || aligned16(a[q].gates)) && aligned16(a[q].W_hh);
+  if (aligned && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns)) return launch_rnn_forward_persist(a, ns, s);
   SkinnyArgs k[SKINNY_MAX_BATCH];
   for (int i = 0; i < a[0].T; ++i) {
     for (int q = 0; q < ns; ++q) rnn_forward_step_args(a[q], i, k[q]);
@@ -243,7 +247,11 @@ int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
     for (int q = 0; q < ns; ++q) CVAE_TRY(rnn_backward_large(arr[q], s));
     return 0;
   }
-  if (rnn_persist_bwd_supported(arr[0].cell, arr[0].T, arr[0].R, arr[0].H, ns)) return launch_rnn_backward_persist(arr, ns, s);
+  bool aligned = true;
+  for (int q = 0; q < ns; ++q)
+    aligned = aligned && aligned16(arr[q].dgx) && (!arr[q].dgh || aligned16(arr[q].dgh)) && aligned16(arr[q].W_hh);
+  if (aligned && rnn_persist_bwd_supported(arr[0].cell, arr[0].T, arr[0].R, arr[0].H, ns))
+    return launch_rnn_backward_persist(arr, ns, s);
   // ---- one launch per step (for all sequences): dh_{t-1} product with the previous step's cell backward fused in
   const int T = arr[0].T, H = arr[0].H, R = arr[0].R;
   const int G = arr[0].cell == CELL_GRU ? 3 : 4;

@@ -87,9 +87,13 @@ class FlatAdam(object):
                 uniq.append(v)
         # embedding first: the alias segment is [0, V*E)
         uniq.sort(key=lambda t: 0 if t is emb else 1)
-        n = sum(p.numel() for p in uniq)
+        # every parameter starts on a 16-byte boundary (the kernels read weights with 16-byte loads; a
+        # vocabulary such as PTB's 10002 would otherwise misalign everything after the first V-sized bias);
+        # the padding elements are zero with zero gradient and take no part in anything
+        pad4 = lambda k: (k + 3) // 4 * 4
+        n = sum(pad4(p.numel()) for p in uniq)
         dev = uniq[0].device
-        self.params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -103,7 +107,7 @@ class FlatAdam(object):
             self.gviews.append(self.grads[off:off + k].view_as(p.data))
             p.grad = self.gviews[-1]
             self.views.append(p)
-            off += k
+            off += pad4(k)
         self.sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0

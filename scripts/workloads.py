@@ -1,0 +1,56 @@
+"""Short single-GPU timing of every BASELINE.json configuration shape (synthetic corpora):
+PTB / Yelp / Yahoo text Coupled-VAE, Switchboard dialogue Coupled-CVAE, and the scale-up shape.
+usage: python scripts/workloads.py [names...]   (default: all)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
+import torch
+from cvae_amd import _lib, data, harness
+dev = torch.device('cuda:0'); _lib.init(0)
+
+CONFIGS = {
+    # name: (model, cell, batch, K, steps, eval batches)
+    'ptb': ('vae-couple', 'lstm', 32, 100, 20, 2),
+    'yelp': ('vae-couple', 'lstm', 32, 500, 20, 2),
+    'yahoo': ('vae-couple', 'lstm', 32, 500, 20, 2),
+    'switchboard': ('cvae-couple', 'lstm', 32, 100, 20, 2),
+    # configs[4] is an 8-GPU job (batch 512, K = 1000): one GPU's share is 64 sentences and 125 samples
+    'scaleup': ('vae-couple', 'lstm', 64, 124, 3, 1),
+}
+names = sys.argv[1:] or list(CONFIGS)
+for name in names:
+    model, cell, B, K, steps, nev = CONFIGS[name]
+    s = data.SHAPES[name]
+    hp = harness.HParams(model=model, cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'], batch_size=B,
+                         euclidean_dist=(name == 'yahoo'), lambda_couple=2.0 if name == 'switchboard' else 0.1)
+    tr = harness.Trainer(hp, dev, seed=0)
+    tr.iter_num = 20000
+    n = steps + 2
+    mk = lambda seed, cnt: data.Corpus(data.synthetic_sentences(B * cnt, s['V'], s['mu'], s['sigma'], s['cap'], seed=seed))
+    if hp.is_dialog():
+        posts, resps = mk(1, n), mk(2, n)
+        batches = [harness.dialog_batch(posts, resps, range(i * B, (i + 1) * B), dev) for i in range(n)]
+        toks = [resps.n_tokens(range(i * B, (i + 1) * B)) for i in range(n)]
+        ep, er = mk(3, nev + 1), mk(4, nev + 1)
+        ev = [harness.dialog_batch(ep, er, range(i * B, (i + 1) * B), dev) for i in range(nev + 1)]
+    else:
+        c = mk(1, n)
+        batches = [harness.text_batch(c, range(i * B, (i + 1) * B), dev, sort_rows=True) for i in range(n)]
+        toks = [c.n_tokens(range(i * B, (i + 1) * B)) for i in range(n)]
+        e = mk(3, nev + 1)
+        ev = [harness.text_batch(e, range(i * B, (i + 1) * B), dev, truncate=False) for i in range(nev + 1)]
+    for i in range(2):
+        tr.train_step(batches[i])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(2, n):
+        tr.train_step(batches[i])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert _lib.query('cvae_persist_status') == 0
+    tr.iw_eval(ev[:1], K)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m, _ = tr.iw_eval(ev[1:], K)
+    torch.cuda.synchronize(); de = time.perf_counter() - t0
+    print('%-12s %-12s B=%-4d train %8.2f ms/step %10.0f tokens/s | IW-NLL K=%-5d %8.2f sentences/s  (nll %.2f)'
+          % (name, model, B, dt / steps * 1e3, sum(toks[2:]) / dt, K, m['n'] / de, m['nll']), flush=True)
+    del tr, batches, ev
+    torch.cuda.empty_cache()

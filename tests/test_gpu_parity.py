@@ -360,3 +360,29 @@ def test_iw_nll_vs_oracle_and_row_chunking(dev, cell):
     for other in outs[1:]:
         for a, b in zip(outs[0][:3], other[:3]):
             assert rel(a, b) < 1e-6
+
+
+def test_train_step_with_vocab_not_multiple_of_four(dev):
+    """PTB's vocabulary is 10002: the V-sized biases must not misalign the parameters packed after them
+    (the whole-sequence recurrent kernels read weights with 16-byte loads).  One step vs the oracle."""
+    from cvae_amd import modules, data, harness
+    V, E, H, Z, B = 1002, 32, 128, 8, 32
+    hp = harness.HParams(model='vae-couple', cell='lstm', V=V, E=E, H=H, Z=Z, dropout=0.0)
+    tr = harness.Trainer(hp, dev, seed=3)
+    for p_ in tr.opt.views:
+        assert p_.data_ptr() % 16 == 0 and p_.grad.data_ptr() % 16 == 0
+    c = data.Corpus(data.synthetic_sentences(B, V, 2.5, 0.4, 30, seed=6))
+    batch = harness.text_batch(c, range(B), dev)
+    P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    eps = torch.randn(1, B, Z, generator=torch.Generator().manual_seed(2))
+    modules.set_noise_source(modules.ReplayNoise({'eps': [eps], 'eps_couple': [eps]}))
+    try:
+        res = tr.forward_backward(batch)
+    finally:
+        modules.set_noise_source(None)
+    cb = {k: v.cpu() for k, v in batch.items()}
+    cfg = dict(latent_dim=Z, lambda_kl=res['lambda_kl'], lambda_couple=hp.lambda_couple,
+               lambda_seq_couple=hp.lambda_seq_couple, euclidean_dist=False)
+    with torch.no_grad():
+        out = O.train_forward(P, 'vae-couple', 'lstm', cb, {'eps': eps[0]}, cfg)
+    assert close(res['tot'], out['tot'], LOSS_TOL)
