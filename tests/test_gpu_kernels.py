@@ -53,6 +53,11 @@ GEMM_CASES = [
     (6432, 200, 1024, 0, 0, 0, 0, 0),      # dX = dG W_ih
     (2048, 512, 3000, 1, 0, 0, 0, 0),      # decoder dW_hh: four 128-column tiles
     (200, 512, 3000, 1, 0, 0, 0, 1),       # dW_c accumulate
+    # x W^T with >= 192 output tiles (128x128 tiles): K tails, ragged edges, epilogues
+    (6400, 2048, 400, 0, 1, 1, 0, 0),      # decoder input projection: K tail of 16
+    (2100, 1540, 200, 0, 1, 1, 1, 0),      # ragged M / N, bias + tanh, K tail of 8
+    (3000, 1100, 36, 0, 1, 0, 0, 1),       # short K with a 4-wide tail, accumulate
+    (1600, 2048, 512, 0, 1, 0, 2, 0),      # relu
 ]
 
 
