@@ -316,8 +316,10 @@ struct DecTrainFwd {
 
 // nd decoders with identical shapes (the stochastic and the coupled deterministic one) advance
 // in the same launches: their recurrences are independent.
+// skip_prefix (the LM's decoder, CV/Modules/lm.py:78-100): no prefix step, h_0 = 0.  The recurrence then
+// covers internal steps 1..T starting from a zeroed slot 1; step 0's buffers are left unused.
 static int decoder_train_forward(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go, const float* emb,
-                                 const DecTrainFwd* dd, float* hp, hipStream_t s) {
+                                 const DecTrainFwd* dd, float* hp, hipStream_t s, int skip_prefix = 0) {
   const int G = gates_of(cell);
   const long BH = (long)B * Hd, GH = (long)G * Hd;
   RnnFwd f[SKINNY_MAX_BATCH] = {};
@@ -330,6 +332,13 @@ static int decoder_train_forward(int nd, int cell, int B, int T, int E, int Hd, 
     CVAE_TRY(linear_nt(q.X, q.w[0], 2L * E, q.w[2], ACT_NONE, (T + 1) * B, (int)GH, 2 * E, q.xproj, s));
     f[d].cell = cell; f[d].T = T + 1; f[d].R = B; f[d].H = Hd; f[d].xproj = q.xproj; f[d].xmod = B;
     f[d].W_hh = q.w[1]; f[d].b_hh = q.w[3]; f[d].hs = q.hs; f[d].cs = q.cs; f[d].gates = q.gates; f[d].hp_scratch = hp;
+    if (skip_prefix) {
+      CVAE_TRY(launch_zero(q.hs, 2 * BH, s));
+      if (q.cs) CVAE_TRY(launch_zero(q.cs, 2 * BH, s));
+      CVAE_TRY(launch_zero(q.gates, (long)B * 4 * Hd, s));
+      f[d].T = T; f[d].xproj = q.xproj + (long)B * GH; f[d].hs = q.hs + BH; f[d].cs = q.cs ? q.cs + BH : nullptr;
+      f[d].gates = q.gates + (long)B * 4 * Hd; f[d].init_in_place = 1;
+    }
   }
   CVAE_TRY(launch_rnn_forward_multi(f, nd, s));
   for (int d = 0; d < nd; ++d) {
@@ -519,7 +528,7 @@ struct DecBwd {
 };
 
 static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go,
-                                 const DecBwd* dd, float* demb, hipStream_t s) {
+                                 const DecBwd* dd, float* demb, hipStream_t s, int skip_prefix = 0) {
   const int G = gates_of(cell), T1 = T + 1;
   const long BH = (long)B * Hd, GH = (long)G * Hd;
   RnnBwd r[SKINNY_MAX_BATCH] = {};
@@ -574,6 +583,14 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
     r[d].dhs = dhs; r[d].hs = q.hs; r[d].cs = q.cs; r[d].gates = q.gates; r[d].W_hh = q.w[1];
     r[d].dgx = dgx[d]; r[d].dgh = (cell == CELL_GRU) ? dgh[d] : nullptr;
     r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
+    if (skip_prefix) {      // internal steps 1..T only; step 0 contributes nothing
+      CVAE_TRY(launch_zero(dgx[d], (long)B * GH, s));
+      if (cell == CELL_GRU) CVAE_TRY(launch_zero(dgh[d], (long)B * GH, s));
+      r[d].T = T; r[d].dhs = dhs + BH; r[d].hs = q.hs + BH; r[d].cs = q.cs ? q.cs + BH : nullptr;
+      r[d].gates = q.gates + (long)B * 4 * Hd; r[d].dgx = dgx[d] + (long)B * GH;
+      r[d].dgh = (cell == CELL_GRU) ? dgh[d] + (long)B * GH : nullptr;
+      if (r[d].zero_after) r[d].zero_after -= B;          // za (target steps) instead of za + 1
+    }
   }
   CVAE_TRY(launch_rnn_backward_multi(r, nd, s));
   for (int d = 0; d < nd; ++d) {
@@ -601,6 +618,30 @@ int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, cons
   CVAE_REQUIRE(go && demb, "decoder_backward: null operand");
   DecBwd q = {mask_in, mask_out, w, X, hs, cs, gates, hdrop, final, dfinal, dinit, dw, scratch};
   return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream));
+}
+
+// LM decoder (CV/Modules/lm.py:78-100): the training branch without the prefix step (h_0 = 0).  The caller
+// passes init = 0 and W_ih = [W_ih_lm | 0], which makes the conditioning half of the input vanish.
+int cvae_decoder_forward_noprefix(int cell, int B, int T, int E, int Hd, int64_t V, const float* init,
+                                  const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
+                                  const float* const* w, float* X, float* xproj, float* hs, float* cs, float* gates,
+                                  float* hdrop, float* final, void* stream) {
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_forward_noprefix: bad cell");
+  CVAE_REQUIRE(B > 0 && B <= SKINNY_MAX_ROWS && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_forward_noprefix: bad shape");
+  CVAE_REQUIRE(init && go && emb && w, "decoder_forward_noprefix: null operand");
+  DecTrainFwd q = {init, mask_in, mask_out, w, X, xproj, hs, cs, gates, hdrop, final};
+  return decoder_train_forward(1, cell, B, T, E, Hd, go, emb, &q, nullptr, S(stream), 1);
+}
+int cvae_decoder_backward_noprefix(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                                   const float* mask_in, const float* mask_out, const float* const* w, const float* X,
+                                   const float* hs, const float* cs, const float* gates, const float* hdrop,
+                                   const float* final, const float* dfinal, float* dinit, float* const* dw,
+                                   float* demb, float* scratch, void* stream) {
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_backward_noprefix: bad cell");
+  CVAE_REQUIRE(B > 0 && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward_noprefix: bad shape");
+  CVAE_REQUIRE(go && demb, "decoder_backward_noprefix: null operand");
+  DecBwd q = {mask_in, mask_out, w, X, hs, cs, gates, hdrop, final, dfinal, dinit, dw, scratch};
+  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream), 1);
 }
 
 int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,

@@ -38,6 +38,8 @@ SIGNATURES = {
     'cvae_decoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     'cvae_decoder_forward_sorted': [I, I, I, I, I, I, L] + [P] * 13,
     'cvae_targets_sentence_major': [P, I, I, I, P, P],
+    'cvae_decoder_forward_noprefix': [I, I, I, I, I, L] + [P] * 14,
+    'cvae_decoder_backward_noprefix': [I, I, I, I, I, L] + [P] * 16,
     'cvae_decoder_greedy_scratch': [I, I, I, I, I, L],
     'cvae_decoder_greedy': [I, I, I, I, I, L, P, P, P, P, P, P, I, P, P, P],
     'cvae_decoder_forward_n': [I, I, I, I, I, I, L] + [P] * 14,

@@ -163,8 +163,9 @@ class Trainer(object):
             else:
                 logits, prior, post = out
             kl = ops.kl_div(post.loc, post.scale, prior.loc, prior.scale)
-        elif hp.model == 'dae':                       # CV/Experiment.py:680-692: reconstruction loss only
-            logits, _ = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
+        elif hp.model in ('dae', 'lm'):               # CV/Experiment.py:666-692: reconstruction loss only
+            out = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
+            logits = out if hp.model == 'lm' else out[0]
             seq = m.criterionSeq(logits, batch['eos'], keep_batch=True).mean(0)
             return {'seq': seq, 'tot': seq, 'lambda_kl': 0.0}
         else:

@@ -456,6 +456,72 @@ class DAE(_TextBase):
             return xent, xent + inf, inf, latent
 
 
+class LMDecoder(nn.Module):
+    """CV/Modules/lm.py:28-100 (its own Decoder class): GRU over the word embeddings alone, h_0 = 0, no
+    latent input; `toInit` exists in the state_dict but is never used.  The reference builds the LSTM
+    flavour with input_size 2E and then feeds E-wide inputs (it cannot run), so only GRU is offered."""
+
+    def __init__(self, voc_size, latent_dim, emb_dim, hid_dim, n_layer, dropout, max_len, beam_size, WEAtt_type,
+                 embedding):
+        super(LMDecoder, self).__init__()
+        assert n_layer == 1 and WEAtt_type == 'none'
+        assert not settings.use_lstm, 'Modules/lm.py cannot run with use_lstm (input width mismatch in the reference)'
+        self.voc_size, self.latent_dim, self.emb_dim, self.hid_dim = voc_size, latent_dim, emb_dim, hid_dim
+        self.n_layers, self.dropout, self.max_len, self.beam_size = n_layer, dropout, max_len, beam_size
+        self.WEAtt_type, self.use_lstm = WEAtt_type, False
+        self.drop = nn.Dropout(dropout)
+        self.Embedding = embedding
+        self.toInit = nn.Sequential(nn.Linear(latent_dim, emb_dim), nn.ReLU(), nn.Linear(emb_dim, emb_dim))
+        self.GRU = nn.GRU(input_size=emb_dim, hidden_size=hid_dim, num_layers=n_layer, bidirectional=False)
+        self.W_c = nn.Linear(hid_dim, emb_dim)
+        self.ToVocab = nn.Linear(emb_dim, voc_size)
+
+    def final_states(self, helper, train):
+        w = _rnn_weights(self.GRU) + [self.W_c.weight, self.W_c.bias]
+        B, T = helper.shape
+        mask_in = mask_out = None
+        if train:
+            dev = helper.device
+            mask_in = _noise.dropout_mask((T, B, self.emb_dim), self.dropout, dev, 'dec_in_drop')
+            mask_out = _noise.dropout_mask((T, B, self.hid_dim), self.dropout, dev, 'dec_out_drop')
+        return ops.decoder_noprefix(ops.GRU, helper, mask_in, mask_out, self.Embedding.weight, w)
+
+    def forward(self, init_states, latent_vector, helper, test_lm=False):
+        if not (self.training or test_lm):
+            raise NotImplementedError('the LM does not decode (Experiment.sample_from_prior returns early for it)')
+        final = self.final_states(helper, self.training and not test_lm)
+        return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, helper.shape[0])
+
+
+class LM(nn.Module):
+    """CV/Modules/lm.py:190-256."""
+
+    def __init__(self, hid_dim, latent_dim, dec_layers, dropout, dec_max_len, beam_size, WEAtt_type, decoder_emb,
+                 pad_id, **_unused):
+        super(LM, self).__init__()
+        self.voc_size, self.emb_dim = decoder_emb.num_embeddings, decoder_emb.embedding_dim
+        self.hid_dim, self.dec_layers, self.dropout, self.n_dir = hid_dim, dec_layers, dropout, 2
+        self.dec_max_len, self.beam_size, self.WEAtt_type, self.latent_dim = dec_max_len, beam_size, WEAtt_type, latent_dim
+        self.Decoder = LMDecoder(voc_size=self.voc_size, latent_dim=latent_dim, emb_dim=self.emb_dim,
+                                 hid_dim=hid_dim * self.n_dir, n_layer=dec_layers, dropout=dropout, max_len=dec_max_len,
+                                 beam_size=beam_size, WEAtt_type=WEAtt_type, embedding=decoder_emb)
+        self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
+
+    def forward(self, go, sent_len=None, bare=None):
+        if not self.training:
+            raise NotImplementedError()
+        return self.Decoder(None, None, go)
+
+    def test_lm(self, go, sent_len, bare, eos, n_sample):
+        """lm.py:218-235: xent of one deterministic pass; kl = 0, nll = xent, latent = zeros (B, Z)."""
+        with torch.no_grad():
+            go, eos, bare = _truncate_eval(go, eos, bare, sent_len)
+            final = self.Decoder.final_states(go, False)
+            xent = ops.proj_ce(final, self.Decoder.ToVocab.weight, self.Decoder.ToVocab.bias, eos, self.criterionSeq.pad)
+            kl = torch.zeros_like(xent)
+            return xent, xent + kl, kl, torch.zeros(go.shape[0], self.latent_dim)
+
+
 class VAE_COUPLE(_TextBase):
     """CV/Modules/vae_couple.py:374-741."""
 
@@ -581,6 +647,6 @@ class CVAE_COUPLE(_DialogBase):
 
 # Experiment.__init__ (CV/Experiment.py:96-383) builds beta-vae*, cyc-anneal-vae* and surprising-fix* from the
 # very same VAE / VAE_COUPLE classes; they differ in the lambda_KL schedule / KL term (harness).
-MODEL_CLASSES = {'vae': VAE, 'vae-couple': VAE_COUPLE, 'cvae': CVAE, 'cvae-couple': CVAE_COUPLE, 'dae': DAE,
+MODEL_CLASSES = {'vae': VAE, 'vae-couple': VAE_COUPLE, 'cvae': CVAE, 'cvae-couple': CVAE_COUPLE, 'dae': DAE, 'lm': LM,
                  'beta-vae': VAE, 'beta-vae-couple': VAE_COUPLE, 'cyc-anneal-vae': VAE,
                  'cyc-anneal-vae-couple': VAE_COUPLE, 'surprising-fix': VAE, 'surprising-fix-couple': VAE_COUPLE}

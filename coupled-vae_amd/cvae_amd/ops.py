@@ -212,6 +212,60 @@ class DecoderFn(torch.autograd.Function):
         return (None, None, dinit, None, None, None, demb, *dw)
 
 
+class DecoderNoPrefixFn(torch.autograd.Function):
+    """The LM's decoder (CV/Modules/lm.py:78-100): the training branch without the prefix step, h_0 = 0.
+    Same buffers as DecoderFn(train=True); masks may be None (evaluation)."""
+
+    @staticmethod
+    def forward(ctx, cell, init, go, mask_in, mask_out, emb, *w):
+        init, go, emb = _c(init), _c(go), _c(emb)
+        w = [_c(t) for t in w]
+        B, E = init.shape
+        T = go.shape[1]
+        V, Hd, G = emb.shape[0], w[1].shape[1], gates_of(cell)
+        hs = _f((T + 2, B, Hd), emb)
+        cs = _f((T + 2, B, Hd), emb) if cell == LSTM else None
+        final = _f((T, B, E), emb)
+        X = _f((T + 1, B, 2 * E), emb)
+        xproj = _f((T + 1, B, G * Hd), emb)
+        gates = _f((T + 1, B, 4 * Hd), emb)
+        hdrop = _f((T, B, Hd), emb) if mask_out is not None else None
+        warr = ptr_array(w)
+        call('cvae_decoder_forward_noprefix', cell, B, T, E, Hd, V, ptr(init), ptr(go), ptr(emb), ptr(mask_in),
+             ptr(mask_out), warr, ptr(X), ptr(xproj), ptr(hs), ptr(cs), ptr(gates), ptr(hdrop), ptr(final), stream())
+        ctx.cell, ctx.dims = cell, (B, T, E, Hd, V)
+        ctx.save_for_backward(go, mask_in, mask_out, emb, X, hs, cs, gates, hdrop, final, *w)
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal):
+        go, mask_in, mask_out, emb, X, hs, cs, gates, hdrop, final = ctx.saved_tensors[:10]
+        w = list(ctx.saved_tensors[10:])
+        B, T, E, Hd, V = ctx.dims
+        dfinal = _c(dfinal)
+        dinit = _f((B, E), emb)
+        dw = [torch.empty_like(t) for t in w]
+        demb = torch.zeros_like(emb)
+        scratch = _f((query('cvae_decoder_backward_scratch', ctx.cell, B, T, E, Hd),), emb)
+        warr, dwarr = ptr_array(w), ptr_array(dw)
+        call('cvae_decoder_backward_noprefix', ctx.cell, B, T, E, Hd, V, ptr(go), ptr(mask_in), ptr(mask_out), warr,
+             ptr(X), ptr(hs), ptr(cs), ptr(gates), ptr(hdrop), ptr(final), ptr(dfinal), ptr(dinit), dwarr, ptr(demb),
+             ptr(scratch), stream())
+        return (None, None, None, None, None, demb, *dw)
+
+
+def decoder_noprefix(cell, go, mask_in, mask_out, emb, w):
+    """LM decoder: w = [W_ih (G*Hd, E), W_hh, b_ih, b_hh, W_c, b_c]; the input has no conditioning half, which
+    the kernels see as init = 0 and W_ih = [W_ih | 0] (autograd slices the gradient back).  mask_in (T,B,E)."""
+    B, T = go.shape
+    E = emb.shape[1]
+    W_ih = torch.cat([w[0], torch.zeros_like(w[0])], 1)
+    init = torch.zeros((B, E), dtype=torch.float32, device=emb.device)
+    if mask_in is not None:
+        mask_in = torch.cat([mask_in, torch.ones_like(mask_in)], 2)
+    return DecoderNoPrefixFn.apply(cell, init, go, mask_in, mask_out, emb, W_ih, *w[1:])
+
+
 def decoder(cell, train, init, go, mask_in, mask_out, emb, w):
     """w: [W_ih, W_hh, b_ih, b_hh, W_c, b_c] -> final (T,R,E)."""
     if not train:

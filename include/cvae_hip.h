@@ -108,6 +108,19 @@ int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, in
                                 const int64_t* go, const float* emb, const int* live_sent, const float* const* w,
                                 float* X, float* xproj, float* xadd, float* hp, float* hs, float* cs, float* final,
                                 void* stream);
+/* ---- f4 (sibling variant lm, Modules/lm.py:78-100): the training branch of the decoder without the
+ * prefix step (h_0 = 0).  The LM's input has no conditioning half: the caller passes init = 0 and
+ * W_ih = [W_ih_lm | 0] ([G*Hd, 2E]); buffers and arguments as cvae_decoder_forward(train=1) /
+ * cvae_decoder_backward (step 0's slots are zero-filled and unused; dinit comes back zero). */
+int cvae_decoder_forward_noprefix(int cell, int B, int T, int E, int Hd, int64_t V, const float* init,
+                                  const int64_t* go, const float* emb, const float* mask_in, const float* mask_out,
+                                  const float* const* w, float* X, float* xproj, float* hs, float* cs, float* gates,
+                                  float* hdrop, float* final, void* stream);
+int cvae_decoder_backward_noprefix(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
+                                   const float* mask_in, const float* mask_out, const float* const* w, const float* X,
+                                   const float* hs, const float* cs, const float* gates, const float* hdrop,
+                                   const float* final, const float* dfinal, float* dinit, float* const* dw,
+                                   float* demb, float* scratch, void* stream);
 /* ---- f3: greedy branch of Decoder.forward (Modules/decoder.py:176-201, Modules/vae_couple.py:
  * 173-201; used by sample_from_prior / decode_from / gen_interps).  T = max_len steps, no early stop
  * (as the reference): y_t = argmax_v ToVocab(tanh(W_c h_t))[v] with entry mask_id set to -inf first

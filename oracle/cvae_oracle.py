@@ -192,6 +192,28 @@ def decoder_final(P, pre, cell, init, go, mask_in=None, mask_out=None):
     return torch.tanh(outs @ P[pre + 'W_c.weight'].t() + P[pre + 'W_c.bias'])
 
 
+def lm_decoder_final(P, pre, go, mask_in=None, mask_out=None):
+    """The LM's decoder (CV/Modules/lm.py:78-100), GRU flavour: a GRU over the word embeddings alone,
+    h_0 = 0, then tanh(W_c drop(h_t)).  go (B,T) -> final (T,B,E); mask_in (T,B,E)."""
+    rp = pre + 'GRU.'
+    W_ih, W_hh = P[rp + 'weight_ih_l0'], P[rp + 'weight_hh_l0']
+    b_ih, b_hh = P[rp + 'bias_ih_l0'], P[rp + 'bias_hh_l0']
+    B, T = go.shape
+    x = P[pre + 'Embedding.weight'][go].transpose(0, 1)            # (T,B,E)
+    if mask_in is not None:
+        x = x * mask_in
+    xp = x @ W_ih.t() + b_ih
+    h = x.new_zeros(B, W_hh.shape[1])
+    outs = []
+    for t in range(T):
+        h = _gru_step(xp[t], h, W_hh, b_hh)
+        outs.append(h)
+    outs = torch.stack(outs)
+    if mask_out is not None:
+        outs = outs * mask_out
+    return torch.tanh(outs @ P[pre + 'W_c.weight'].t() + P[pre + 'W_c.bias'])
+
+
 def seq_xent(P, pre, final, eos, pad=PAD):
     """ToVocab + SeqLoss(keep_batch=True): CV/Modules/vae_couple.py:119,
     CV/Modules/Losses/SeqLoss.py:36-44.  final (T,B,E), eos (B,T) -> (B,)."""
@@ -295,6 +317,13 @@ def train_forward(P, model, cell, batch, noise, cfg):
     g = noise.get
     free_bits = cfg.get('lambda_fb') if model.startswith('surprising-fix') else None
     model = arch_of(model)
+    if model == 'lm':
+        # LM.forward (CV/Modules/lm.py:237-256): the decoder alone, reconstruction loss only
+        assert cell == 'gru', 'Modules/lm.py only runs with GRU cells'
+        final = lm_decoder_final(P, 'Decoder.', batch['go'], g('dec_in_drop'), g('dec_out_drop'))
+        seq = seq_xent(P, 'Decoder.', final, batch['eos'])
+        out.update(final=final, seq_per_sent=seq, seq=seq.mean(0), tot=seq.mean(0))
+        return out
     if model == 'dae':
         # DAE.forward (CV/Modules/dae.py): deterministic latent = toLatent(last), no KL term
         go, eos = batch['go'], batch['eos']
@@ -503,6 +532,11 @@ def decoder_greedy(P, prefix, cell, init, first, T, mask_id=3):
         cur = torch.argmax(logits, dim=1)
         out.append(cur)
     return torch.stack(out, 1)
+
+
+def lm_test_lm(P, batch):
+    """LM.test_lm (CV/Modules/lm.py:218-235): xent (B,) of one pass; the reference returns kl = 0, nll = xent."""
+    return seq_xent(P, 'Decoder.', lm_decoder_final(P, 'Decoder.', batch['go']), batch['eos'])
 
 
 def dae_test_lm(P, cell, batch):

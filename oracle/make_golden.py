@@ -58,6 +58,7 @@ JOBS = [
     ('text_cyc-anneal-vae-couple_lstm_tiny', 'Coupled-VAE', 'ptb', 'cyc-anneal-vae-couple', 'lstm',
      dict(TINY, annealing_start=0, annealing_step=80)),
     ('text_dae_gru_tiny', 'Coupled-VAE', 'ptb', 'dae', 'gru', TINY),
+    ('text_lm_gru_tiny', 'Coupled-VAE', 'ptb', 'lm', 'gru', TINY),
 ]
 BASE_MODEL = {'beta-vae': 'vae', 'cyc-anneal-vae': 'vae', 'cyc-anneal-vae-couple': 'vae-couple'}
 
@@ -67,6 +68,7 @@ NOISE_ORDER = {
     'vae-couple': ['enc_drop', 'eps', 'eps_couple', 'dec_in_drop', 'dec_out_drop',
                    'decc_in_drop', 'decc_out_drop'],
     'dae': ['enc_drop', 'dec_in_drop', 'dec_out_drop'],
+    'lm': ['dec_in_drop', 'dec_out_drop'],
     'cvae': ['post_enc_drop', 'resp_enc_drop', 'eps_prior', 'eps', 'dec_in_drop', 'dec_out_drop'],
     'cvae-couple': ['post_enc_drop', 'resp_enc_drop', 'eps_prior', 'eps', 'eps_couple',
                     'dec_in_drop', 'dec_out_drop', 'decc_in_drop', 'decc_out_drop'],
@@ -344,7 +346,9 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             assert (kind == 'eps') == nm.startswith('eps'), (nm, kind)
             out[p + 'noise/' + nm] = t.squeeze(0).numpy() if kind == 'eps' else t.numpy()
         fw = rec['fwd'][it]
-        if base == 'dae':
+        if base == 'lm':
+            logits, dist = fw, None                     # LM.forward returns the logits tensor itself
+        elif base == 'dae':
             logits, dist = fw[0], None
             out[p + 'latent'] = fw[1].detach().numpy()
         elif tree == 'Coupled-VAE':
@@ -370,7 +374,7 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         if coupled:
             out[p + 'seq_c_per_sent'] = rec['seq'][it * nseq + 1].numpy()
             out[p + 'euc'] = rec['euc'][it].numpy()
-        if base != 'dae':
+        if base not in ('dae', 'lm'):
             out[p + 'kl_elem'] = rec['kl'][it].numpy()
         out[p + 'tot'] = np.float64(rec['tot'][it])
         out[p + 'lambda_kl'] = np.float64(steps[it][4])   # 0 in the base fixtures: iter 1,2 << annealing_start
@@ -401,6 +405,20 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         print('wrote', out_path, '%.1f KB' % (os.path.getsize(out_path) / 1024))
 
     from torch.utils.data import DataLoader
+    if base == 'lm':
+        # LM.test_lm (Modules/lm.py:218-235): one pass, kl = 0, nll = xent
+        ae.train(False)
+        vb = next(iter(DataLoader(exp.val_set, batch_size=shp['B'], shuffle=False)))
+        bare, go, eos, ln = vb
+        with torch.no_grad():
+            xent, nll, kl, lat = ae.test_lm(bare=bare, sent_len=ln, go=go, eos=eos, n_sample=2)
+        assert bool((kl == 0).all()) and bool((nll == xent).all())
+        out['iw/lm/bare'], out['iw/lm/go'], out['iw/lm/eos'], out['iw/lm/len'] = \
+            bare.numpy(), go.numpy(), eos.numpy(), ln.numpy()
+        out['iw/lm/xent'] = xent.numpy()
+        sd_np('eval/')
+        finish()
+        return
     if base == 'dae':
         # DAE.test_lm (Modules/dae.py): one deterministic decode, nll = kl = inf by construction
         ae.train(False)

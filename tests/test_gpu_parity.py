@@ -63,7 +63,7 @@ def test_train_steps_match_reference(dev, name):
             res = tr.forward_backward(batch)
             assert abs(res['lambda_kl'] - float(g.np(p + 'lambda_kl'))) < 1e-12   # schedule of the variant
             assert close(res['seq'], g.t(p + 'seq_per_sent').mean(), LOSS_TOL)
-            if m['model'] != 'dae':
+            if m['model'] not in ('dae', 'lm'):
                 assert close(res['kl'], g.t(p + 'kl_elem').sum(1).mean(), LOSS_TOL)
             if O.is_couple(m['model']):
                 assert close(res['seq_c'], g.t(p + 'seq_c_per_sent').mean(), LOSS_TOL)
@@ -100,11 +100,15 @@ def test_forward_outputs_match_reference(dev, name):
                 logits, prior, post = out[0], out[1], out[2]
                 assert rel(prior.loc, g.t(p + 'mu_prior')) < 1e-4 and rel(prior.scale, g.t(p + 'sigma_prior')) < 1e-4
                 extra = out[3:]
+            elif m['model'] == 'lm':
+                logits, post, extra = tr.model(go=batch['go'], sent_len=batch['len'], bare=batch['bare']), None, ()
             else:
                 out = tr.model(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
                 logits, post = out[0], out[1]
                 extra = out[4:]
-        if m['model'] == 'dae':
+        if m['model'] == 'lm':
+            pass
+        elif m['model'] == 'dae':
             assert rel(post, g.t(p + 'latent')) < 1e-4                 # (logits, latent_vector)
         else:
             assert rel(post.loc, g.t(p + 'mu')) < 1e-4 and rel(post.scale, g.t(p + 'sigma')) < 1e-4
@@ -162,7 +166,18 @@ def test_greedy_decode_vs_oracle_ptb_shape(dev, cell):
     assert n_diff == 0, '%d sentences differ from the fp64 oracle' % n_diff
 
 
-VAES = [n for n in names() if '_dae_' not in n]          # fixtures with a posterior: IW-NLL, corpus loop, MI
+VAES = [n for n in names() if '_dae_' not in n and '_lm_' not in n]   # fixtures with a posterior: IW-NLL, corpus loop, MI
+
+
+@pytest.mark.parametrize('name', [n for n in names() if '_lm_' in n])
+def test_lm_test_lm_matches_reference(dev, name):
+    g = Golden(name)
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    b = {k: v.to(dev) for k, v in g.batch('iw/lm/').items()}
+    xent, nll, kl, latent = tr.model.test_lm(bare=b['bare'], sent_len=b['len'], go=b['go'], eos=b['eos'], n_sample=2)
+    assert rel(xent, g.t('iw/lm/xent')) < LOSS_TOL
+    assert torch.equal(nll, xent) and not kl.any() and tuple(latent.shape) == (b['go'].shape[0], g.meta['Z'])
 
 
 @pytest.mark.parametrize('name', [n for n in names() if '_dae_' in n])
