@@ -215,35 +215,70 @@ int cvae_linear_backward(const float* x, const float* W, const float* y, const f
 }
 
 // ------------------------------------------------------------------------------ encoder
+// ne encoders with the same (B, L, E, H) and cell (a text model has one; the dialogue model's post and
+// response encoders are padded to a common L by the caller): all 2*ne directions advance in the same
+// launches -- one whole-sequence kernel launch instead of ne.
+struct EncFwd {
+  const int64_t* ids; const int64_t* len; const float* mask; const int64_t* mask_rows; const float* const* w;
+  float *X, *xproj, *hs, *cs, *gates, *last;
+};
+static int encoder_forward_impl(int ne, int cell, int B, int L, int E, int H, const float* emb, const EncFwd* ee,
+                                hipStream_t s) {
+  CVAE_REQUIRE(ne >= 1 && 2 * ne <= SKINNY_MAX_BATCH, "encoder_forward: %d encoders (max %d)", ne, SKINNY_MAX_BATCH / 2);
+  const int G = gates_of(cell);
+  RnnFwd f[SKINNY_MAX_BATCH] = {};
+  for (int e = 0; e < ne; ++e) {
+    const EncFwd& q = ee[e];
+    CVAE_REQUIRE(q.ids && q.len && q.w && q.X && q.xproj && q.hs && q.last, "encoder_forward: null operand");
+    CVAE_REQUIRE(cell == CELL_GRU || q.cs, "encoder_forward: LSTM needs cs");
+    CVAE_TRY(launch_embed(L, B, E, 0, 0, q.ids, B, emb, nullptr, q.mask, q.mask_rows, q.X, s));
+    for (int d = 0; d < 2; ++d) {
+      const float* W_ih = q.w[4 * d + 0]; const float* W_hh = q.w[4 * d + 1];
+      const float* b_ih = q.w[4 * d + 2]; const float* b_hh = q.w[4 * d + 3];
+      float* xp = q.xproj + (long)d * L * B * G * H;
+      CVAE_TRY(linear_nt(q.X, W_ih, E, b_ih, ACT_NONE, L * B, G * H, E, xp, s));
+      RnnFwd& r = f[2 * e + d];
+      r.cell = cell; r.T = L; r.R = B; r.H = H; r.reverse = d;
+      r.xproj = xp; r.xmod = B; r.W_hh = W_hh; r.b_hh = b_hh; r.lengths = q.len;
+      r.hs = q.hs + (long)d * (L + 1) * B * H;
+      r.cs = q.cs ? q.cs + (long)d * (L + 1) * B * H : nullptr;
+      r.gates = q.gates ? q.gates + (long)d * L * B * 4 * H : nullptr;
+    }
+  }
+  CVAE_TRY(launch_rnn_forward_multi(f, 2 * ne, s));       // every direction advances in the same launches
+  for (int e = 0; e < ne; ++e)
+    for (int d = 0; d < 2; ++d) {
+      const float* fin = f[2 * e + d].hs + (long)(d ? 0 : L) * B * H;
+      CVAE_TRY(launch_copy_cols(B, H, fin, H, 0, ee[e].last, 2L * H, d * H, s));
+    }
+  return 0;
+}
+
 int cvae_encoder_forward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
                          const float* emb, const float* mask, const int64_t* mask_rows, const float* const* w,
                          float* X, float* xproj, float* hs, float* cs, float* gates, float* last, void* stream) {
-  hipStream_t s = S(stream);
   CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_forward: bad cell");
   CVAE_REQUIRE(B > 0 && L > 0 && E > 0 && H > 0 && V > 0, "encoder_forward: bad shape B=%d L=%d E=%d H=%d", B, L, E, H);
   CVAE_REQUIRE(B <= SKINNY_MAX_ROWS, "encoder_forward: B=%d > %d not supported", B, SKINNY_MAX_ROWS);
-  CVAE_REQUIRE(ids && len && emb && w && X && xproj && hs && last, "encoder_forward: null operand");
-  CVAE_REQUIRE(cell == CELL_GRU || cs, "encoder_forward: LSTM needs cs");
-  const int G = gates_of(cell);
-  CVAE_TRY(launch_embed(L, B, E, 0, 0, ids, B, emb, nullptr, mask, mask_rows, X, s));
-  RnnFwd f[2] = {};
-  for (int d = 0; d < 2; ++d) {
-    const float* W_ih = w[4 * d + 0]; const float* W_hh = w[4 * d + 1];
-    const float* b_ih = w[4 * d + 2]; const float* b_hh = w[4 * d + 3];
-    float* xp = xproj + (long)d * L * B * G * H;
-    CVAE_TRY(linear_nt(X, W_ih, E, b_ih, ACT_NONE, L * B, G * H, E, xp, s));
-    f[d].cell = cell; f[d].T = L; f[d].R = B; f[d].H = H; f[d].reverse = d;
-    f[d].xproj = xp; f[d].xmod = B; f[d].W_hh = W_hh; f[d].b_hh = b_hh; f[d].lengths = len;
-    f[d].hs = hs + (long)d * (L + 1) * B * H;
-    f[d].cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
-    f[d].gates = gates ? gates + (long)d * L * B * 4 * H : nullptr;
-  }
-  CVAE_TRY(launch_rnn_forward_multi(f, 2, s));       // both directions advance in the same launches
-  for (int d = 0; d < 2; ++d) {
-    const float* fin = f[d].hs + (long)(d ? 0 : L) * B * H;
-    CVAE_TRY(launch_copy_cols(B, H, fin, H, 0, last, 2L * H, d * H, s));
-  }
-  return 0;
+  CVAE_REQUIRE(emb, "encoder_forward: null operand");
+  EncFwd q = {ids, len, mask, mask_rows, w, X, xproj, hs, cs, gates, last};
+  return encoder_forward_impl(1, cell, B, L, E, H, emb, &q, S(stream));
+}
+
+int cvae_encoder_forward_n(int ne, int cell, int B, int L, int E, int H, int64_t V, const int64_t* const* ids,
+                           const int64_t* const* len, const float* emb, const float* const* mask,
+                           const int64_t* const* mask_rows, const float* const* w, float* const* X,
+                           float* const* xproj, float* const* hs, float* const* cs, float* const* gates,
+                           float* const* last, void* stream) {
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_forward_n: bad cell");
+  CVAE_REQUIRE(ne >= 1 && 2 * ne <= SKINNY_MAX_BATCH && B > 0 && B <= SKINNY_MAX_ROWS && L > 0 && E > 0 && H > 0 && V > 0,
+               "encoder_forward_n: bad shape ne=%d B=%d L=%d E=%d H=%d", ne, B, L, E, H);
+  CVAE_REQUIRE(ids && len && emb && mask && mask_rows && w && X && xproj && hs && cs && gates && last,
+               "encoder_forward_n: null pointer array");
+  EncFwd q[SKINNY_MAX_BATCH / 2];
+  for (int e = 0; e < ne; ++e)
+    q[e] = EncFwd{ids[e], len[e], mask[e], mask_rows[e], w + 8 * e, X[e], xproj[e], hs[e], cs[e], gates[e], last[e]};
+  return encoder_forward_impl(ne, cell, B, L, E, H, emb, q, S(stream));
 }
 
 int64_t cvae_encoder_backward_scratch(int cell, int B, int L, int E, int H) {
@@ -252,60 +287,101 @@ int64_t cvae_encoder_backward_scratch(int cell, int B, int L, int E, int H) {
   return 2 * (2 * (int64_t)L * B * G * H + 5 * (int64_t)B * H + G * (int64_t)H * H) + (int64_t)L * B * E;
 }
 
+struct EncBwd {
+  const int64_t* ids; const int64_t* len; const float* mask; const int64_t* mask_rows; const float* const* w;
+  const float *X, *hs, *cs, *gates, *dlast;
+  float* const* dw; float* scratch;
+};
+static int encoder_backward_impl(int ne, int cell, int B, int L, int E, int H, const EncBwd* ee, float* demb,
+                                 hipStream_t s) {
+  CVAE_REQUIRE(ne >= 1 && 2 * ne <= SKINNY_MAX_BATCH, "encoder_backward: %d encoders (max %d)", ne, SKINNY_MAX_BATCH / 2);
+  const int G = gates_of(cell);
+  const long LBG = (long)L * B * G * H, BH = (long)B * H;
+  const long per_dir = 2 * LBG + 5 * BH + (long)G * H * H;
+  RnnBwd r[SKINNY_MAX_BATCH] = {};
+  float* dgx[SKINNY_MAX_BATCH]; float* dgh[SKINNY_MAX_BATCH];
+  for (int e = 0; e < ne; ++e) {
+    const EncBwd& q = ee[e];
+    CVAE_REQUIRE(q.ids && q.len && q.w && q.X && q.hs && q.gates && q.dlast && q.dw && q.scratch,
+                 "encoder_backward: null operand");
+    for (int d = 0; d < 2; ++d) {
+      const int i = 2 * e + d;
+      float* base = q.scratch + d * per_dir;
+      dgx[i] = base; dgh[i] = base + LBG;
+      float* dh_last = base + 2 * LBG;
+      float* dh0 = dh_last + BH; float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
+      float* whhT = dc_tmp + BH;
+      CVAE_TRY(launch_copy_cols(B, H, q.dlast, 2L * H, d * H, dh_last, H, 0, s));
+      r[i].cell = cell; r[i].T = L; r[i].R = B; r[i].H = H; r[i].reverse = d;
+      r[i].dh_last = dh_last; r[i].hs = q.hs + (long)d * (L + 1) * B * H;
+      r[i].cs = q.cs ? q.cs + (long)d * (L + 1) * B * H : nullptr;
+      r[i].gates = q.gates + (long)d * L * B * 4 * H; r[i].W_hh = q.w[4 * d + 1]; r[i].lengths = q.len;
+      r[i].dgx = dgx[i]; r[i].dgh = (cell == CELL_GRU) ? dgh[i] : nullptr;
+      r[i].dh0 = dh0; r[i].dc0 = dc0; r[i].dh_tmp = dh_tmp; r[i].dc_tmp = dc_tmp; r[i].whhT = whhT;
+    }
+  }
+  CVAE_TRY(launch_rnn_backward_multi(r, 2 * ne, s));
+  // padded steps (t >= len[b]) have exactly zero pre-activation gradients: leave them out
+  const bool use_live = live_rows_enabled() && (long)L * B >= 1024;
+  const long per_list = 16 + (long)L * B;
+  int* buf = nullptr;
+  if (use_live) CVAE_TRY(lib_rows(ne * per_list, &buf));
+  for (int e = 0; e < ne; ++e) {
+    const EncBwd& q = ee[e];
+    float* dX = q.scratch + 2 * per_dir;
+    LiveRows live = {nullptr, nullptr};
+    const LiveRows* lr = nullptr;
+    if (use_live) {
+      int* lb = buf + e * per_list;
+      CVAE_TRY(launch_live_rows_tm(L, B, q.len, 0, lb + 16, lb, s));
+      live.rows = lb + 16; live.n = lb;
+      lr = &live;
+      CVAE_TRY(launch_zero(dX, (long)L * B * E, s));
+    }
+    for (int d = 0; d < 2; ++d) {
+      const int i = 2 * e + d;
+      const float* W_ih = q.w[4 * d + 0];
+      const float* dgh_eff = (cell == CELL_GRU) ? dgh[i] : dgx[i];
+      // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
+      const float* hprev = r[i].hs + (d ? BH : 0);
+      CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, q.dw[4 * d + 1], 0, s, nullptr, lr));
+      CVAE_TRY(grad_weight(dgx[i], (long)G * H, q.X, E, L * B, G * H, E, q.dw[4 * d + 0], 0, s, q.dw[4 * d + 2], lr));
+      // LSTM: both bias vectors see the same pre-activation gradient
+      if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, q.dw[4 * d + 3], s));
+      else CVAE_TRY(launch_copy(q.dw[4 * d + 3], q.dw[4 * d + 2], (long)G * H, s));
+      CVAE_TRY(grad_input(dgx[i], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s, lr));
+    }
+    CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, q.ids, dX, q.mask, q.mask_rows, demb, s));
+  }
+  return 0;
+}
+
 int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const int64_t* ids, const int64_t* len,
                           const float* mask, const int64_t* mask_rows, const float* const* w, const float* X,
                           const float* hs, const float* cs, const float* gates, const float* dlast,
                           float* const* dw, float* demb, float* scratch, void* stream) {
-  hipStream_t s = S(stream);
   CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_backward: bad cell");
   CVAE_REQUIRE(B > 0 && L > 0 && E > 0 && H > 0 && V > 0, "encoder_backward: bad shape");
-  CVAE_REQUIRE(ids && len && w && X && hs && gates && dlast && dw && demb && scratch, "encoder_backward: null operand");
-  const int G = gates_of(cell);
-  const long LBG = (long)L * B * G * H, BH = (long)B * H;
-  const long per_dir = 2 * LBG + 5 * BH + (long)G * H * H;
-  float* dX = scratch + 2 * per_dir;
-  RnnBwd r[2] = {};
-  float* dgx[2]; float* dgh[2];
-  for (int d = 0; d < 2; ++d) {
-    float* base = scratch + d * per_dir;
-    dgx[d] = base; dgh[d] = base + LBG;
-    float* dh_last = base + 2 * LBG;
-    float* dh0 = dh_last + BH; float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
-    float* whhT = dc_tmp + BH;
-    CVAE_TRY(launch_copy_cols(B, H, dlast, 2L * H, d * H, dh_last, H, 0, s));
-    r[d].cell = cell; r[d].T = L; r[d].R = B; r[d].H = H; r[d].reverse = d;
-    r[d].dh_last = dh_last; r[d].hs = hs + (long)d * (L + 1) * B * H;
-    r[d].cs = cs ? cs + (long)d * (L + 1) * B * H : nullptr;
-    r[d].gates = gates + (long)d * L * B * 4 * H; r[d].W_hh = w[4 * d + 1]; r[d].lengths = len;
-    r[d].dgx = dgx[d]; r[d].dgh = (cell == CELL_GRU) ? dgh[d] : nullptr;
-    r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
-  }
-  CVAE_TRY(launch_rnn_backward_multi(r, 2, s));
-  // padded steps (t >= len[b]) have exactly zero pre-activation gradients: leave them out
-  LiveRows live = {nullptr, nullptr};
-  const LiveRows* lr = nullptr;
-  if (live_rows_enabled() && (long)L * B >= 1024) {
-    int* buf = nullptr;
-    CVAE_TRY(lib_rows(16 + (long)L * B, &buf));
-    CVAE_TRY(launch_live_rows_tm(L, B, len, 0, buf + 16, buf, s));
-    live.rows = buf + 16; live.n = buf;
-    lr = &live;
-    CVAE_TRY(launch_zero(dX, (long)L * B * E, s));
-  }
-  for (int d = 0; d < 2; ++d) {
-    const float* W_ih = w[4 * d + 0];
-    const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
-    // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
-    const float* hprev = r[d].hs + (d ? BH : 0);
-    CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, dw[4 * d + 1], 0, s, nullptr, lr));
-    CVAE_TRY(grad_weight(dgx[d], (long)G * H, X, E, L * B, G * H, E, dw[4 * d + 0], 0, s, dw[4 * d + 2], lr));
-    // LSTM: both bias vectors see the same pre-activation gradient
-    if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, dw[4 * d + 3], s));
-    else CVAE_TRY(launch_copy(dw[4 * d + 3], dw[4 * d + 2], (long)G * H, s));
-    CVAE_TRY(grad_input(dgx[d], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s, lr));
-  }
-  CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ids, dX, mask, mask_rows, demb, s));
-  return 0;
+  CVAE_REQUIRE(demb, "encoder_backward: null operand");
+  EncBwd q = {ids, len, mask, mask_rows, w, X, hs, cs, gates, dlast, dw, scratch};
+  return encoder_backward_impl(1, cell, B, L, E, H, &q, demb, S(stream));
+}
+
+int cvae_encoder_backward_n(int ne, int cell, int B, int L, int E, int H, int64_t V, const int64_t* const* ids,
+                            const int64_t* const* len, const float* const* mask, const int64_t* const* mask_rows,
+                            const float* const* w, const float* const* X, const float* const* hs,
+                            const float* const* cs, const float* const* gates, const float* const* dlast,
+                            float* const* dw, float* demb, float* const* scratch, void* stream) {
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "encoder_backward_n: bad cell");
+  CVAE_REQUIRE(ne >= 1 && 2 * ne <= SKINNY_MAX_BATCH && B > 0 && L > 0 && E > 0 && H > 0 && V > 0,
+               "encoder_backward_n: bad shape ne=%d B=%d L=%d E=%d H=%d", ne, B, L, E, H);
+  CVAE_REQUIRE(ids && len && mask && mask_rows && w && X && hs && cs && gates && dlast && dw && demb && scratch,
+               "encoder_backward_n: null pointer array");
+  EncBwd q[SKINNY_MAX_BATCH / 2];
+  for (int e = 0; e < ne; ++e)
+    q[e] = EncBwd{ids[e], len[e], mask[e], mask_rows[e], w + 8 * e, X[e], hs[e], cs[e], gates[e], dlast[e],
+                  dw + 8 * e, scratch[e]};
+  return encoder_backward_impl(ne, cell, B, L, E, H, q, demb, S(stream));
 }
 
 // ------------------------------------------------------------------------------ decoder

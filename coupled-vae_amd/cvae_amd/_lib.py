@@ -33,6 +33,8 @@ SIGNATURES = {
     'cvae_encoder_forward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P],
     'cvae_encoder_backward_scratch': [I, I, I, I, I],
     'cvae_encoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cvae_encoder_forward_n': [I, I, I, I, I, I, L] + [P] * 13,
+    'cvae_encoder_backward_n': [I, I, I, I, I, I, L] + [P] * 14,
     'cvae_decoder_forward': [I, I, I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     'cvae_decoder_backward_scratch': [I, I, I, I, I],
     'cvae_decoder_backward': [I, I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],

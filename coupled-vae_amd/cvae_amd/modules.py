@@ -132,8 +132,7 @@ class Encoder(nn.Module):
         else:
             self.GRU = nn.GRU(**kw)
 
-    def last_flat(self, bare, length, noise_name='enc_drop'):
-        """(B, 2H) = [h_fwd | h_bwd]."""
+    def _operands(self, bare, length, noise_name):
         rnn = self.LSTM if self.use_lstm else self.GRU
         w = _rnn_weights(rnn) + _rnn_weights(rnn, True)
         B, L = bare.shape
@@ -143,8 +142,28 @@ class Encoder(nn.Module):
             mask = _noise.dropout_mask((L, B, self.emb_dim), self.dropout, bare.device, noise_name)
             if mask is not None:
                 _, mask_rows = ops.sort_resort(length)
+        return w, mask, mask_rows
+
+    def last_flat(self, bare, length, noise_name='enc_drop'):
+        """(B, 2H) = [h_fwd | h_bwd]."""
+        w, mask, mask_rows = self._operands(bare, length, noise_name)
         cell = ops.LSTM if self.use_lstm else ops.GRU
         return ops.encoder(cell, bare, length, mask, mask_rows, self.Embedding.weight, w)
+
+    @staticmethod
+    def last_flat_pair(enc_a, bare_a, len_a, noise_a, enc_b, bare_b, len_b, noise_b):
+        """Both encoders of the dialogue model in the same launches when they share the embedding and shape;
+        otherwise one after the other.  The noise tape is consumed in the same order either way."""
+        same = (enc_a.Embedding is enc_b.Embedding and enc_a.hid_dim == enc_b.hid_dim
+                and enc_a.use_lstm == enc_b.use_lstm and bare_a.shape[0] == bare_b.shape[0]
+                and settings.pair_encoders)
+        if not same:
+            return enc_a.last_flat(bare_a, len_a, noise_a), enc_b.last_flat(bare_b, len_b, noise_b)
+        w_a, mask_a, rows_a = enc_a._operands(bare_a, len_a, noise_a)
+        w_b, mask_b, rows_b = enc_b._operands(bare_b, len_b, noise_b)
+        cell = ops.LSTM if enc_a.use_lstm else ops.GRU
+        return ops.encoder_pair(cell, bare_a, len_a, mask_a, rows_a, w_a, bare_b, len_b, mask_b, rows_b, w_b,
+                                enc_a.Embedding.weight)
 
     def forward(self, bare, length):
         last = self.last_flat(bare, length)
@@ -562,9 +581,9 @@ class _DialogBase(nn.Module):
     _to_init_seq = _TextBase._to_init_seq
 
     def _encode(self, post_bare, post_len, resp_bare, resp_len):
-        post = self.PostEncoder.last_flat(post_bare, post_len, 'post_enc_drop')
+        post, resp = Encoder.last_flat_pair(self.PostEncoder, post_bare, post_len, 'post_enc_drop',
+                                            self.RespEncoder, resp_bare, resp_len, 'resp_enc_drop')
         post_repr = ops.linear(post, self.PostRepr.weight, self.PostRepr.bias)
-        resp = self.RespEncoder.last_flat(resp_bare, resp_len, 'resp_enc_drop')
         return post, post_repr, torch.cat([resp, post], dim=1)
 
     def test_lm(self, post_bare, post_len, resp_go, resp_len, resp_bare, resp_eos, n_sample):

@@ -157,6 +157,73 @@ def encoder(cell, ids, length, mask, mask_rows, emb, w):
     return EncoderFn.apply(cell, ids, length, mask, mask_rows, emb, *w)
 
 
+class EncoderPairFn(torch.autograd.Function):
+    """Two encoders over the same embedding in lock-step (CC/Modules/cvae_couple.py's post and response
+    encoders, CC/Modules/encoder.py:41-70 each): both are padded to the longer L -- steps past a row's
+    length are carries, so the result does not change -- and all four directions share their launches."""
+
+    @staticmethod
+    def forward(ctx, cell, ids_a, len_a, mask_a, rows_a, ids_b, len_b, mask_b, rows_b, emb, *w):
+        emb = _c(emb)
+        w = [_c(t) for t in w]
+        B = ids_a.shape[0]
+        L = max(ids_a.shape[1], ids_b.shape[1])
+        V, E = emb.shape
+        H = w[1].shape[1]
+        G = gates_of(cell)
+        need_grad = any(ctx.needs_input_grad)
+
+        def padded(ids, mask):
+            l = ids.shape[1]
+            if l < L:
+                ids = torch.cat([ids, ids.new_zeros((B, L - l))], dim=1)
+                if mask is not None:
+                    mask = torch.cat([mask, mask.new_ones((L - l, B, E))], dim=0)
+            return _c(ids), (_c(mask) if mask is not None else None)
+
+        ids_a, mask_a = padded(ids_a, mask_a)
+        ids_b, mask_b = padded(ids_b, mask_b)
+        len_a, len_b = _c(len_a), _c(len_b)
+        X = _f((2, L, B, E), emb)
+        xproj = _f((2, 2, L, B, G * H), emb)
+        hs = _f((2, 2, L + 1, B, H), emb)
+        cs = _f((2, 2, L + 1, B, H), emb) if cell == LSTM else None
+        gates = _f((2, 2, L, B, 4 * H), emb) if need_grad else None
+        last = _f((2, B, 2 * H), emb)
+        pair = lambda t: [t[0], t[1]] if t is not None else [None, None]
+        keep = [ptr_array(x) for x in ([ids_a, ids_b], [len_a, len_b], [mask_a, mask_b], [rows_a, rows_b], w,
+                                       pair(X), pair(xproj), pair(hs), pair(cs), pair(gates), pair(last))]
+        call('cvae_encoder_forward_n', 2, cell, B, L, E, H, V, keep[0], keep[1], ptr(emb), keep[2], keep[3], keep[4],
+             keep[5], keep[6], keep[7], keep[8], keep[9], keep[10], stream())
+        if need_grad:
+            ctx.cell, ctx.dims = cell, (B, L, E, H, V)
+            ctx.save_for_backward(ids_a, ids_b, len_a, len_b, mask_a, mask_b, rows_a, rows_b, emb, X, hs, cs, gates, *w)
+        return last[0], last[1]
+
+    @staticmethod
+    def backward(ctx, dlast_a, dlast_b):
+        ids_a, ids_b, len_a, len_b, mask_a, mask_b, rows_a, rows_b, emb, X, hs, cs, gates = ctx.saved_tensors[:13]
+        w = list(ctx.saved_tensors[13:])
+        B, L, E, H, V = ctx.dims
+        zero = lambda d: _c(d) if d is not None else torch.zeros((B, 2 * H), device=emb.device, dtype=emb.dtype)
+        dlast = [zero(dlast_a), zero(dlast_b)]
+        dw = [torch.empty_like(t) for t in w]
+        demb = torch.zeros_like(emb)
+        n = query('cvae_encoder_backward_scratch', ctx.cell, B, L, E, H)
+        scratch = _f((2, n), emb)
+        pair = lambda t: [t[0], t[1]] if t is not None else [None, None]
+        keep = [ptr_array(x) for x in ([ids_a, ids_b], [len_a, len_b], [mask_a, mask_b], [rows_a, rows_b], w,
+                                       pair(X), pair(hs), pair(cs), pair(gates), dlast, dw, pair(scratch))]
+        call('cvae_encoder_backward_n', 2, ctx.cell, B, L, E, H, V, keep[0], keep[1], keep[2], keep[3], keep[4],
+             keep[5], keep[6], keep[7], keep[8], keep[9], keep[10], ptr(demb), keep[11], stream())
+        return (None,) * 9 + (demb,) + tuple(dw)
+
+
+def encoder_pair(cell, ids_a, len_a, mask_a, rows_a, w_a, ids_b, len_b, mask_b, rows_b, w_b, emb):
+    """-> (last_a, last_b), each (B, 2H); w_a / w_b as in `encoder`."""
+    return EncoderPairFn.apply(cell, ids_a, len_a, mask_a, rows_a, ids_b, len_b, mask_b, rows_b, emb, *w_a, *w_b)
+
+
 # --------------------------------------------------------------------------- decoder
 class DecoderFn(torch.autograd.Function):
     """Teacher-forced decoder up to `final` (T,R,E): CV/Modules/vae_couple.py:86-115."""

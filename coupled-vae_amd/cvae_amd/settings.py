@@ -6,6 +6,7 @@ class _Settings(object):
     n_sample_chunk = 2        # _n_sample (CC/Modules/vae_couple.py:20): eps is drawn in (2,B,Z) chunks
     iw_max_rows = 16384       # rows (samples x sentences) decoded per pass in IW evaluation
     sort_eval = True          # IW eval: sentence-major rows ordered by length, finished rows are skipped (exact)
+    pair_encoders = True      # dialogue model: post and response encoders in the same launches (ops.encoder_pair)
     shard_samples = False     # multi-GPU IW eval: shard the K samples of every sentence over ranks (dist_utils)
     truncate_eval = True      # cut T to max(len)+1 in test_lm (exact: pad targets weigh 0)
 

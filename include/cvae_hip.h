@@ -76,6 +76,23 @@ int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const
                           const float* mask, const int64_t* mask_rows, const float* const* w, const float* X,
                           const float* hs, const float* cs, const float* gates, const float* dlast,
                           float* const* dw, float* demb, float* scratch, void* stream);
+/* ne (1 or 2) encoders over the SAME embedding, cell, B, L, E, H in the same launches: the dialogue
+ * model's post and response encoders (CC/Modules/cvae_couple.py forward: PostEncoder then
+ * RespEncoder, CC/Modules/encoder.py:41-70 each).  The caller pads the shorter batch's ids (any valid
+ * id) and mask (ones) to the common L; steps past len[b] are carries, so results equal the separate
+ * calls.  Every pointer argument is a host array of ne device pointers laid out as in the
+ * single-encoder call (entries of mask, mask_rows, cs, gates may be NULL as there); w / dw hold
+ * 8 pointers per encoder (w[8*e + i]); scratch[e] as for cvae_encoder_backward. */
+int cvae_encoder_forward_n(int ne, int cell, int B, int L, int E, int H, int64_t V, const int64_t* const* ids,
+                           const int64_t* const* len, const float* emb, const float* const* mask,
+                           const int64_t* const* mask_rows, const float* const* w, float* const* X,
+                           float* const* xproj, float* const* hs, float* const* cs, float* const* gates,
+                           float* const* last, void* stream);
+int cvae_encoder_backward_n(int ne, int cell, int B, int L, int E, int H, int64_t V, const int64_t* const* ids,
+                            const int64_t* const* len, const float* const* mask, const int64_t* const* mask_rows,
+                            const float* const* w, const float* const* X, const float* const* hs,
+                            const float* const* cs, const float* const* gates, const float* const* dlast,
+                            float* const* dw, float* demb, float* const* scratch, void* stream);
 
 /* ---- a7: Decoder.forward, teacher-forcing branch (Modules/vae_couple.py:86-115,
  * Modules/decoder.py:85-107) up to final = tanh(W_c drop(h_t)) -- the vocab projection is

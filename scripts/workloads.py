@@ -5,7 +5,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
 import torch
-from cvae_amd import _lib, data, harness
+from cvae_amd import _lib, data, harness, settings
+settings.pair_encoders = os.environ.get('PAIR_ENCODERS', '1') != '0'
 dev = torch.device('cuda:0'); _lib.init(0)
 
 CONFIGS = {
@@ -13,7 +14,7 @@ CONFIGS = {
     'ptb': ('vae-couple', 'lstm', 32, 100, 20, 2),
     'yelp': ('vae-couple', 'lstm', 32, 500, 20, 2),
     'yahoo': ('vae-couple', 'lstm', 32, 500, 20, 2),
-    'switchboard': ('cvae-couple', 'lstm', 32, 100, 20, 2),
+    'switchboard': ('cvae-couple', 'lstm', 32, 100, 40, 8),
     # configs[4] is an 8-GPU job (batch 512, K = 1000): one GPU's share is 64 sentences and 125 samples
     'scaleup': ('vae-couple', 'lstm', 64, 124, 3, 1),
 }

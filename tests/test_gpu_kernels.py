@@ -168,6 +168,54 @@ def test_encoder_forward_backward(dev, cell, shape):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
+# (B, L_a, L_b, E, H, V): per-step kernels, whole-sequence kernels with the longer batch first / second
+@pytest.mark.parametrize('shape', [(5, 7, 4, 16, 8, 50), (32, 40, 25, 200, 128, 1000), (19, 12, 23, 40, 256, 300)])
+def test_encoder_pair_matches_separate(dev, cell, shape):
+    """The dialogue model's two encoders in lock-step (cvae_encoder_forward_n / backward_n) against the two
+    single-encoder calls: same last states, same gradients (shared embedding gradient = the sum)."""
+    from cvae_amd import ops
+    B, La, Lb, E, H, V = shape
+    g = torch.Generator().manual_seed(5)
+    c = ops.GRU if cell == 'gru' else ops.LSTM
+    emb = torch.randn(V, E, generator=g).to(dev)
+    side = []
+    for L, seed in ((La, 3), (Lb, 4)):
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        lens[0] = L
+        side.append(dict(ids=torch.randint(0, V, (B, L), generator=g).to(dev), lens=lens.to(dev),
+                         mask=((torch.rand(L, B, E, generator=g) > 0.2).float() / 0.8).to(dev),
+                         rows=ops.sort_resort(lens.to(dev))[1], ws=[w.to(dev) for w in _rnn_params(cell, E, H, True, seed)],
+                         dlast=torch.randn(B, 2 * H, generator=g).to(dev)))
+    for train in (True, False):
+        res = []
+        for paired in (False, True):
+            e = emb.clone().requires_grad_(train)
+            ws = [[w.clone().requires_grad_(train) for w in q['ws']] for q in side]
+            m = [(q['mask'], q['rows']) if train else (None, None) for q in side]
+            a, b = side
+            if paired:
+                la, lb = ops.encoder_pair(c, a['ids'], a['lens'], m[0][0], m[0][1], ws[0],
+                                          b['ids'], b['lens'], m[1][0], m[1][1], ws[1], e)
+            else:
+                la = ops.encoder(c, a['ids'], a['lens'], m[0][0], m[0][1], e, ws[0])
+                lb = ops.encoder(c, b['ids'], b['lens'], m[1][0], m[1][1], e, ws[1])
+            out = [la.detach(), lb.detach()]
+            if train:
+                ((la * a['dlast']).sum() + (lb * b['dlast']).sum()).backward()
+                out += [e.grad] + [w.grad for w in ws[0] + ws[1]]
+            res.append(out)
+        for x, y in zip(*res):
+            assert rel(y, x) < 2e-5
+    # one of the two outputs unused: its gradient arrives as None
+    e = emb.clone().requires_grad_(True)
+    ws = [[w.clone().requires_grad_(True) for w in q['ws']] for q in side]
+    a, b = side
+    la, lb = ops.encoder_pair(c, a['ids'], a['lens'], None, None, ws[0], b['ids'], b['lens'], None, None, ws[1], e)
+    (la * a['dlast']).sum().backward()
+    assert float(ws[1][0].grad.abs().max()) == 0.0 and float(ws[0][0].grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
 @pytest.mark.parametrize('shape', [(5, 8, 16, 16, 50), (32, 30, 200, 256, 1000), (13, 17, 24, 512, 200)])
 def test_decoder_forward_backward(dev, cell, shape):
     from cvae_amd import ops
