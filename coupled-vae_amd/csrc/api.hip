@@ -574,6 +574,88 @@ int cvae_decoder_greedy(int cell, int B, int T, int E, int Hd, int64_t V, const 
   return 0;
 }
 
+// ---- f3: beam branch of Decoder.forward (CV/Modules/decoder.py:114-168; vae_couple.py:122-172).
+// The reference keeps `beam` states of B rows each and loops over them in Python; here the K beams are
+// rows k*B + b of one K*B-row batch, so a step is one pass of the same kernels as the greedy branch plus
+// top-K, the per-sentence selection and a gather of the chosen states.  No host synchronisation.
+// Step 0 has a single source state (B rows).  Sentences never end early (the reference decodes
+// max_len tokens whatever they are).  The reference's branch only runs with the GRU (it indexes the
+// state as one tensor); the LSTM here carries (h, c) the same way.
+static long beam_scratch_floats(int cell, int B, int K, int T, int E, int Hd, int64_t V) {
+  const long G = gates_of(cell), R = (long)K * B;
+  // xinit[R,GH] x0[B,GH] xp[R,GH] X[R,E] fin[R,E] hs 2x[2,R,Hd] cs 2x[2,R,Hd] logits[R,V] lv[R,K] nll 2x[R]
+  // | int: li[R,K] src[R] bp[T,R] tok[T,R] | int64: cur[R]
+  return R * G * Hd * 2 + B * G * Hd + 2 * R * E + 8 * R * Hd + R * V + R * K + 2 * R + R * K + R + 2L * T * R +
+         2 * R + 64;
+}
+int64_t cvae_decoder_beam_scratch(int cell, int B, int K, int T, int E, int Hd, int64_t V) {
+  return beam_scratch_floats(cell, B, K, T, E, Hd, V);
+}
+int cvae_decoder_beam(int cell, int B, int K, int T, int E, int Hd, int64_t V, const float* init, const int64_t* first,
+                      const float* emb, const float* const* w, const float* W_v, const float* b_v, int mask_id,
+                      float* ws, int64_t* out_ids, float* out_nll, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(cell == CELL_GRU || cell == CELL_LSTM, "decoder_beam: bad cell");
+  CVAE_REQUIRE(B > 0 && K >= 2 && K <= 8 && (long)K * B <= SKINNY_MAX_ROWS && T > 0 && E > 0 && Hd > 0 && V > K &&
+                   V <= INT_MAX,
+               "decoder_beam: bad shape B=%d K=%d T=%d E=%d Hd=%d (2 <= K <= 8, K*B <= %d)", B, K, T, E, Hd,
+               SKINNY_MAX_ROWS);
+  CVAE_REQUIRE(init && first && emb && w && W_v && b_v && ws && out_ids, "decoder_beam: null operand");
+  const int G = gates_of(cell), R = K * B;
+  const float* W_ih = w[0]; const float* W_hh = w[1]; const float* b_ih = w[2]; const float* b_hh = w[3];
+  const float* W_c = w[4]; const float* b_c = w[5];
+  const long GH = (long)G * Hd, RH = (long)R * Hd;
+  float* xinit = ws;                         // [K][B, G*Hd]  W_ih[:, E:] init, one copy per beam
+  float* x0 = xinit + R * GH;                // [B, G*Hd]     W_ih[:, :E] init + b_ih (prefix step)
+  float* xp = x0 + B * GH;                   // [R, G*Hd]
+  float* X = xp + R * GH;                    // [R, E]
+  float* fin = X + (long)R * E;              // [R, E]
+  float* hsb[2] = {fin + (long)R * E, fin + (long)R * E + 2 * RH};       // 2 x [2, R, Hd]
+  float* csb[2] = {hsb[1] + 2 * RH, hsb[1] + 4 * RH};
+  float* logits = csb[1] + 2 * RH;           // [R, V]
+  float* lv = logits + (long)R * V;          // [R, K]
+  float* nll[2] = {lv + (long)R * K, lv + (long)R * K + R};
+  int* li = reinterpret_cast<int*>(nll[1] + R);                          // [R, K]
+  int* src = li + (long)R * K;               // [R]
+  int* bp = src + R;                         // [T, R]
+  int* tok = bp + (long)T * R;               // [T, R]
+  uintptr_t cp = reinterpret_cast<uintptr_t>(tok + (long)T * R);
+  int64_t* cur = reinterpret_cast<int64_t*>((cp + 15) & ~uintptr_t(15));  // [R]
+  const bool lstm = cell == CELL_LSTM;
+
+  CVAE_TRY(linear_nt(init, W_ih + E, 2L * E, nullptr, ACT_NONE, B, (int)GH, E, xinit, s));
+  for (int k = 1; k < K; ++k) CVAE_TRY(launch_copy(xinit + k * B * GH, xinit, B * GH, s));
+  CVAE_TRY(linear_nt(init, W_ih, 2L * E, b_ih, ACT_NONE, B, (int)GH, E, x0, s));
+  RnnFwd f = {};
+  f.cell = cell; f.T = 1; f.R = B; f.H = Hd; f.xproj = x0; f.xmod = B; f.xadd = xinit;
+  f.W_hh = W_hh; f.b_hh = b_hh; f.hs = hsb[0]; f.cs = lstm ? csb[0] : nullptr;
+  CVAE_TRY(launch_rnn_forward(f, s));        // h_0 (B rows at offset B*Hd) from zeros
+  f.xproj = xp; f.init_in_place = 1;
+  CVAE_TRY(launch_copy(reinterpret_cast<float*>(cur), reinterpret_cast<const float*>(first), 2L * B, s));
+  CVAE_TRY(launch_zero(nll[0], 2L * R, s));
+  for (int t = 0; t < T; ++t) {
+    const int ns = t == 0 ? 1 : K, Rt = ns * B;
+    // step 0 continues in buffer 0 behind the prefix step (input = its output slot); later steps
+    // read slot 0 of buffer t & 1 (written by the previous gather) and write its slot 1
+    float* h_in = t == 0 ? hsb[0] + (long)B * Hd : hsb[t & 1];
+    float* c_in = t == 0 ? csb[0] + (long)B * Hd : csb[t & 1];
+    float* h_out = h_in + (long)Rt * Hd;
+    float* c_out = c_in + (long)Rt * Hd;
+    CVAE_TRY(launch_embed(1, Rt, E, 0, 0, cur, Rt, emb, nullptr, nullptr, nullptr, X, s));
+    CVAE_TRY(linear_nt(X, W_ih, 2L * E, b_ih, ACT_NONE, Rt, (int)GH, E, xp, s));
+    f.R = Rt; f.xmod = Rt; f.hs = h_in; f.cs = lstm ? c_in : nullptr;
+    CVAE_TRY(launch_rnn_forward(f, s));
+    CVAE_TRY(linear_nt(h_out, W_c, Hd, b_c, ACT_TANH, Rt, E, Hd, fin, s));
+    CVAE_TRY(linear_nt(fin, W_v, E, b_v, ACT_NONE, Rt, (int)V, E, logits, s));
+    CVAE_TRY(launch_logsoftmax_topk(Rt, (int)V, K, logits, V, mask_id, lv, li, s));
+    CVAE_TRY(launch_beam_merge(B, K, ns, t, lv, li, nll[t & 1], nll[(t + 1) & 1], src, cur, bp, tok, s));
+    CVAE_TRY(launch_beam_gather(B, K, Hd, src, h_out, hsb[(t + 1) & 1], s));
+    if (lstm) CVAE_TRY(launch_beam_gather(B, K, Hd, src, c_out, csb[(t + 1) & 1], s));
+  }
+  CVAE_TRY(launch_beam_backtrack(B, K, T, bp, tok, nll[T & 1], out_ids, out_nll, s));
+  return 0;
+}
+
 int cvae_decoder_forward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const float* const* init,
                            const int64_t* go, const float* emb, const float* const* mask_in,
                            const float* const* mask_out, const float* const* w, float* const* X,

@@ -357,6 +357,155 @@ int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, 
   return 0;
 }
 
+// ---- f3: beam branch of Decoder.forward (CV/Modules/decoder.py:114-168; vae_couple.py:122-172) -----------
+// Per row: log_softmax over V with entry `mask_id` at -inf (decoder.py:138-142), then the K largest
+// entries in descending order (torch.topk, decoder.py:143; ties go to the lower index here).  One block
+// per row; K + 2 passes over the row (V floats from L2): max, sum, then K times "the best entry that
+// comes strictly after the previous pick in (value desc, index asc) order" -- no exclusion list.
+__device__ __forceinline__ void block_best(float& v, int& i, float* sv, int* si) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_down(v, off, 64);
+    const int oi = __shfl_down(i, off, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  __syncthreads();                                   // sv / si of the previous round are consumed
+  if (lane == 0) { sv[wave] = v; si[wave] = i; }
+  __syncthreads();
+  v = sv[0]; i = si[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (sv[w] > v || (sv[w] == v && si[w] < i)) { v = sv[w]; i = si[w]; }
+}
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(int V, int K, const float* __restrict__ logits, long ld,
+                                                              int mask_id, float* __restrict__ lv,
+                                                              int* __restrict__ li) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ float ssum[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (long)r * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const float x = (v == mask_id) ? -INFINITY : row[v];
+    if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+  }
+  block_best(best, bi, sv, si);
+  const float m = best;
+  float sum = 0.f;
+  for (int v = tid; v < V; v += 256)
+    if (v != mask_id) sum += expf(row[v] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) ssum[wave] = sum;
+  __syncthreads();
+  const float lsum = logf(ssum[0] + ssum[1] + ssum[2] + ssum[3]);
+  float pv = best;
+  int pi = bi;
+  for (int j = 0; j < K; ++j) {
+    if (j > 0) {
+      float cv = -INFINITY;
+      int ci = 0x7fffffff;
+      for (int v = tid; v < V; v += 256) {
+        if (v == mask_id) continue;
+        const float x = row[v];
+        const bool after = x < pv || (x == pv && v > pi);
+        if (after && (x > cv || (x == cv && v < ci))) { cv = x; ci = v; }
+      }
+      block_best(cv, ci, sv, si);
+      pv = cv; pi = ci;
+    }
+    if (tid == 0) { lv[(long)r * K + j] = (pv - m) - lsum; li[(long)r * K + j] = pi; }
+  }
+}
+int launch_logsoftmax_topk(int R, int V, int K, const float* logits, long ld, int mask_id, float* lv, int* li,
+                           hipStream_t s) {
+  if (R == 0) return 0;
+  const int choices = V - ((mask_id >= 0 && mask_id < V) ? 1 : 0);
+  CVAE_REQUIRE(K >= 1 && K <= choices, "logsoftmax_topk: K=%d of %d entries", K, choices);
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(R), dim3(256), 0, s, V, K, logits, ld, mask_id, lv, li);
+  CVAE_LAUNCH_CHECK("logsoftmax_topk_kernel");
+  return 0;
+}
+
+// One beam step's selection (decoder.py:148-166).  Rows are beam-major: row k*B + b is beam k of sentence b.
+// Candidate c = k*K + l of sentence b extends source beam k (k < ns) by its l-th best token and costs
+// nll_prev[k][b] - lv[k*B+b][l]; the reference sorts the ns*K candidates of a sentence with Python's
+// stable sort on that cost and keeps the first K, i.e. K times the cheapest remaining candidate, lowest
+// c on ties.  One thread per sentence (ns*K <= 64).  Writes the new cost, the source beam (for the state
+// gather), the token (next input and history) and the back pointer of step t.
+__global__ void beam_merge_kernel(int B, int K, int ns, int t, const float* __restrict__ lv,
+                                  const int* __restrict__ li, const float* __restrict__ nll_prev,
+                                  float* __restrict__ nll_new, int* __restrict__ src, int64_t* __restrict__ cur,
+                                  int* __restrict__ bp, int* __restrict__ tok) {
+  IDX1D(B);
+  const int b = (int)idx;
+  unsigned long long taken = 0ull;
+  const int nc = ns * K;
+  for (int j = 0; j < K; ++j) {
+    float bv = INFINITY;
+    int bc = -1;
+    for (int c = 0; c < nc; ++c) {
+      if ((taken >> c) & 1ull) continue;
+      const int k = c / K, l = c - k * K;
+      const float v = nll_prev[k * B + b] - lv[(long)(k * B + b) * K + l];
+      if (bc < 0 || v < bv) { bv = v; bc = c; }
+    }
+    taken |= 1ull << bc;
+    const int k = bc / K, l = bc - k * K;
+    const int id = li[(long)(k * B + b) * K + l];
+    const int o = j * B + b;
+    nll_new[o] = bv; src[o] = k; cur[o] = id;
+    bp[((long)t * K) * B + o] = k; tok[((long)t * K) * B + o] = id;
+  }
+}
+int launch_beam_merge(int B, int K, int ns, int t, const float* lv, const int* li, const float* nll_prev,
+                      float* nll_new, int* src, int64_t* cur, int* bp, int* tok, hipStream_t s) {
+  CVAE_REQUIRE(B > 0 && K >= 1 && ns >= 1 && ns * K <= 64, "beam_merge: ns=%d K=%d", ns, K);
+  hipLaunchKernelGGL(beam_merge_kernel, GRID1D((long)B), 0, s, B, K, ns, t, lv, li, nll_prev, nll_new, src, cur, bp,
+                     tok);
+  CVAE_LAUNCH_CHECK("beam_merge_kernel");
+  return 0;
+}
+
+// state of the new beams: out[k*B + b] = in[src[k*B + b]*B + b]   (decoder.py:163)
+__global__ void beam_gather_kernel(int B, int K, int H, const int* __restrict__ src, const float* __restrict__ in,
+                                   float* __restrict__ out) {
+  IDX1D((long)K * B * H);
+  const int j = (int)(idx % H);
+  const long o = idx / H;
+  const int b = (int)(o % B);
+  out[idx] = in[((long)src[o] * B + b) * H + j];
+}
+int launch_beam_gather(int B, int K, int H, const int* src, const float* in, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(beam_gather_kernel, GRID1D((long)K * B * H), 0, s, B, K, H, src, in, out);
+  CVAE_LAUNCH_CHECK("beam_gather_kernel");
+  return 0;
+}
+
+// beam[0].sent (decoder.py:168): follow the back pointers from beam 0 of the last step
+__global__ void beam_backtrack_kernel(int B, int K, int T, const int* __restrict__ bp, const int* __restrict__ tok,
+                                      const float* __restrict__ nll, int64_t* __restrict__ out,
+                                      float* __restrict__ out_nll) {
+  IDX1D(B);
+  const int b = (int)idx;
+  int k = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    const long o = ((long)t * K + k) * B + b;
+    out[(long)b * T + t] = tok[o];
+    k = bp[o];
+  }
+  if (out_nll) out_nll[b] = nll[b];
+}
+int launch_beam_backtrack(int B, int K, int T, const int* bp, const int* tok, const float* nll, int64_t* out,
+                          float* out_nll, hipStream_t s) {
+  hipLaunchKernelGGL(beam_backtrack_kernel, GRID1D((long)B), 0, s, B, K, T, bp, tok, nll, out, out_nll);
+  CVAE_LAUNCH_CHECK("beam_backtrack_kernel");
+  return 0;
+}
+
 // Time-major list of the (t, b) pairs with t < za[b] + off, as row ids k = t*B + b in ascending order,
 // and its length.  One block; T is walked in slabs of 256 steps with an LDS scan of the per-step counts.
 __global__ __launch_bounds__(256) void live_rows_tm_kernel(int T, int B, const int64_t* __restrict__ za, int off,

@@ -22,6 +22,13 @@ int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* 
                      hipStream_t s);
 int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s);
 int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s);
+int launch_logsoftmax_topk(int R, int V, int K, const float* logits, long ld, int mask_id, float* lv, int* li,
+                           hipStream_t s);
+int launch_beam_merge(int B, int K, int ns, int t, const float* lv, const int* li, const float* nll_prev,
+                      float* nll_new, int* src, int64_t* cur, int* bp, int* tok, hipStream_t s);
+int launch_beam_gather(int B, int K, int H, const int* src, const float* in, float* out, hipStream_t s);
+int launch_beam_backtrack(int B, int K, int T, const int* bp, const int* tok, const float* nll, int64_t* out,
+                          float* out_nll, hipStream_t s);
 int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, int64_t* out, long out_ld,
                        long out_off, int64_t* cur, hipStream_t s);
 int launch_add_i64(const int64_t* x, int64_t c, int n, int64_t* y, hipStream_t s);

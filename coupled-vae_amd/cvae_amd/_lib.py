@@ -44,6 +44,8 @@ SIGNATURES = {
     'cvae_decoder_backward_noprefix': [I, I, I, I, I, L] + [P] * 16,
     'cvae_decoder_greedy_scratch': [I, I, I, I, I, L],
     'cvae_decoder_greedy': [I, I, I, I, I, L, P, P, P, P, P, P, I, P, P, P],
+    'cvae_decoder_beam_scratch': [I, I, I, I, I, I, L],
+    'cvae_decoder_beam': [I, I, I, I, I, I, L, P, P, P, P, P, P, I, P, P, P, P],
     'cvae_decoder_forward_n': [I, I, I, I, I, I, L] + [P] * 14,
     'cvae_decoder_backward_n': [I, I, I, I, I, I, L] + [P] * 16,
     'cvae_persist_status': [],
@@ -70,7 +72,7 @@ SIGNATURES = {
     'cvae_axpy': [P, F, L, P, P],
 }
 _RESTYPE_LONG = {'cvae_encoder_backward_scratch', 'cvae_decoder_backward_scratch', 'cvae_projce_workspace',
-                 'cvae_decoder_greedy_scratch',
+                 'cvae_decoder_greedy_scratch', 'cvae_decoder_beam_scratch',
                  'cvae_projce_backward_workspace'}
 
 for _name, _args in SIGNATURES.items():

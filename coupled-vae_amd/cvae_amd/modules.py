@@ -8,7 +8,7 @@ parameter containers (identical names, shapes and initialisation order => identi
 state_dict and, for equal seeds, identical initial weights); their forward() is never called.
 All arithmetic goes through libcvae_hip (ops.py).
 
-Out of scope: greedy / beam decoding branches.
+The greedy and beam branches of Decoder.forward are the step-wise entry points cvae_decoder_greedy / _beam.
 """
 import torch
 import torch.nn as nn
@@ -224,11 +224,18 @@ class Decoder(nn.Module):
         return ops.decoder_greedy(cell, init_input, helper[:, 0], self.max_len, self.Embedding.weight, w,
                                   self.ToVocab.weight, self.ToVocab.bias, mask_id=3)
 
+    def beam(self, init_input, helper, return_nll=False):
+        """Beam branch (CV/Modules/decoder.py:114-168; vae_couple.py:122-172) with self.beam_size beams.
+        -> ids (B, max_len) of beam[0]."""
+        rnn = self.LSTM if self.use_lstm else self.GRU
+        w = _rnn_weights(rnn) + [self.W_c.weight, self.W_c.bias]
+        cell = ops.LSTM if self.use_lstm else ops.GRU
+        return ops.decoder_beam(cell, init_input, helper[:, 0], self.max_len, self.beam_size, self.Embedding.weight,
+                                w, self.ToVocab.weight, self.ToVocab.bias, mask_id=3, return_nll=return_nll)
+
     def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None):
         if not (self.training or test_lm):
-            if self.beam_size > 1:
-                raise NotImplementedError('beam search is not accelerated (every shipped config uses beam_size 1)')
-            ids = self.greedy(init_input, helper)
+            ids = self.beam(init_input, helper) if self.beam_size > 1 else self.greedy(init_input, helper)
             # the reference's return format: per sentence, a list of max_len tensors of shape (1,)
             return [[ids[b, t:t + 1] for t in range(ids.shape[1])] for b in range(ids.shape[0])]
         n_sent = helper.shape[0] if _n_sent is None else _n_sent
@@ -378,10 +385,11 @@ class _TextBase(nn.Module):
     def decode_ids(self, latents, go):
         """decode_from (CV/Modules/vae_couple.py:681-696) as an id tensor (B, max_len)."""
         with torch.no_grad():
-            return self.Decoder.greedy(to_init(self._to_init_seq(), latents), go)
+            init = to_init(self._to_init_seq(), latents)
+            return self.Decoder.beam(init, go) if self.Decoder.beam_size > 1 else self.Decoder.greedy(init, go)
 
     def decode_from(self, latents, go):
-        """CV/Modules/vae_couple.py:681-696 / vae.py:299: greedy decode of given latents, reference format."""
+        """CV/Modules/vae_couple.py:681-696 / vae.py:299: greedy (or, with Decoder.beam_size > 1, beam) decode of given latents, reference format."""
         ids = self.decode_ids(latents, go)
         return [[ids[b, t:t + 1] for t in range(ids.shape[1])] for b in range(ids.shape[0])]
 

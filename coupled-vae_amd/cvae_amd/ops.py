@@ -385,6 +385,23 @@ def decoder_greedy(cell, init, first, T, emb, w, W_v, b_v, mask_id=3):
         return out
 
 
+def decoder_beam(cell, init, first, T, K, emb, w, W_v, b_v, mask_id=3, return_nll=False):
+    """Beam search (CV/Modules/decoder.py:114-168) with K beams; arguments as `decoder_greedy`.
+    -> ids (B,T) int64 of the best beam [, its accumulated negative log-likelihood (B,)]."""
+    with torch.no_grad():
+        init, first, emb, W_v, b_v = _c(init), _c(first), _c(emb), _c(W_v), _c(b_v)
+        w = [_c(t) for t in w]
+        B, E = init.shape
+        V, Hd = emb.shape[0], w[1].shape[1]
+        ws = _f((query('cvae_decoder_beam_scratch', cell, B, K, T, E, Hd, V),), emb)
+        out = torch.empty((B, T), dtype=torch.int64, device=emb.device)
+        nll = _f((B,), emb)
+        warr = ptr_array(w)
+        call('cvae_decoder_beam', cell, B, K, T, E, Hd, V, ptr(init), ptr(first), ptr(emb), warr, ptr(W_v), ptr(b_v),
+             int(mask_id), ptr(ws), ptr(out), ptr(nll), stream())
+        return (out, nll) if return_nll else out
+
+
 class DecoderPairFn(torch.autograd.Function):
     """Two training decoders of identical shape (Decoder / DecoderCouple) advanced in lock-step:
     every timestep of both recurrences is one launch (cvae_decoder_forward_n).

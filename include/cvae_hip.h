@@ -148,6 +148,18 @@ int64_t cvae_decoder_greedy_scratch(int cell, int B, int T, int E, int Hd, int64
 int cvae_decoder_greedy(int cell, int B, int T, int E, int Hd, int64_t V, const float* init, const int64_t* first,
                         const float* emb, const float* const* w, const float* W_v, const float* b_v, int mask_id,
                         float* ws, int64_t* out_ids, void* stream);
+/* ---- f3: beam branch of Decoder.forward (Modules/decoder.py:114-168, Modules/vae_couple.py:122-172;
+ * taken when config.beam_size > 1).  K beams per sentence, T = max_len steps, no early stop.  Each
+ * step: log_softmax of the masked logits (entry mask_id at -inf), the K best tokens of every live beam
+ * (torch.topk; ties to the lower id), then per sentence the K cheapest of the ns*K candidates by
+ * accumulated negative log-likelihood, ties in candidate order (source beam, then rank) as Python's
+ * stable sort gives (decoder.py:161).  out_ids[B,T]: beam[0].sent; out_nll[B] (may be NULL): its cost.
+ * 2 <= K <= 8, K*B <= 256.  ws: cvae_decoder_beam_scratch(...) floats, 16-byte aligned.  The
+ * reference's branch fails for the LSTM (state indexed as one tensor); here (h, c) are carried alike. */
+int64_t cvae_decoder_beam_scratch(int cell, int B, int K, int T, int E, int Hd, int64_t V);
+int cvae_decoder_beam(int cell, int B, int K, int T, int E, int Hd, int64_t V, const float* init, const int64_t* first,
+                      const float* emb, const float* const* w, const float* W_v, const float* b_v, int mask_id,
+                      float* ws, int64_t* out_ids, float* out_nll, void* stream);
 int64_t cvae_decoder_backward_scratch(int cell, int B, int T, int E, int Hd);
 /* dfinal[T,B,E] -> dinit[B,E] (overwritten), dw[6] (overwritten), demb[V,E] (ACCUMULATED). */
 int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,

@@ -496,6 +496,74 @@ def iw_from_rows(P, model, cell, batch, eps, xent):
     return xent.mean(0), nll, kl, z.transpose(0, 1)
 
 
+def _decode_fns(P, prefix, cell, mask_id):
+    """(step, logits_of) closures shared by the greedy and beam restatements."""
+    cn = 'GRU' if cell == 'gru' else 'LSTM'
+    W_ih, W_hh = P[prefix + cn + '.weight_ih_l0'], P[prefix + cn + '.weight_hh_l0']
+    b_ih, b_hh = P[prefix + cn + '.bias_ih_l0'], P[prefix + cn + '.bias_hh_l0']
+
+    def step(x, h, c):
+        gi, gh = x @ W_ih.t() + b_ih, h @ W_hh.t() + b_hh
+        if cell == 'gru':
+            ir, iz, inn = gi.chunk(3, 1)
+            hr, hz, hn = gh.chunk(3, 1)
+            r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+            n = torch.tanh(inn + r * hn)
+            return (1 - z) * n + z * h, c
+        i, f, g, o = (gi + gh).chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        return torch.sigmoid(o) * torch.tanh(c), c
+
+    def logits_of(h):
+        final = torch.tanh(h @ P[prefix + 'W_c.weight'].t() + P[prefix + 'W_c.bias'])
+        logits = final @ P[prefix + 'ToVocab.weight'].t() + P[prefix + 'ToVocab.bias']
+        if mask_id is not None and mask_id >= 0:
+            logits[:, mask_id] = -float('inf')
+        return logits
+
+    return step, logits_of, W_hh.shape[1]
+
+
+def decoder_beam(P, prefix, cell, init, first, T, K, mask_id=3):
+    """Beam branch of Decoder.forward (CV/Modules/decoder.py:114-168; vae_couple.py:122-172), eval mode.
+    State per sentence b: up to K beams (h, c, tokens so far, cost).  Each step every beam takes one cell
+    step on [emb(last token), init], scores log_softmax(masked logits), proposes its K best tokens
+    (decoder.py:142-143); the sentence keeps the K cheapest proposals by accumulated cost, ties in proposal
+    order (beam index, then rank) -- Python's stable `sorted` (decoder.py:161).  T steps, no early stop.
+    The reference cannot run this branch with the LSTM; (h, c) are carried alike here.
+    init (B,E), first (B,) -> (ids (B,T) int64 of beam 0, its cost (B,))."""
+    step, logits_of, H = _decode_fns(P, prefix, cell, mask_id)
+    emb = P[prefix + 'Embedding.weight']
+    B = init.shape[0]
+    z = torch.zeros(B, H, dtype=init.dtype)
+    h0, c0 = step(torch.cat([init, init], 1), z, z.clone())
+    # beams[k] = (h (B,H), c (B,H), last token (B,), history: list of (B,) tensors, cost (B,))
+    beams = [(h0, c0, first, [], torch.zeros(B, dtype=init.dtype))]
+    for _ in range(T):
+        props = []                           # per source beam: (h, c, top values (B,K), top ids (B,K), cost (B,))
+        for h, c, last, hist, cost in beams:
+            h, c = step(torch.cat([emb[last], init], 1), h, c)
+            lv, li = torch.topk(torch.log_softmax(logits_of(h), dim=1), K, dim=1)
+            props.append((h, c, lv, li, cost, hist))
+        new = [(torch.empty_like(h0), torch.empty_like(c0), torch.empty(B, dtype=torch.int64),
+                [torch.empty(B, dtype=torch.int64) for _ in range(len(beams[0][3]) + 1)],
+                torch.empty(B, dtype=init.dtype)) for _ in range(K)]
+        for b in range(B):
+            cand = [(float(pr[4][b] - pr[2][b, l]), k, l) for k, pr in enumerate(props) for l in range(K)]
+            order = sorted(range(len(cand)), key=lambda i: cand[i][0])          # stable
+            for j in range(K):
+                _, k, l = cand[order[j]]
+                pr = props[k]
+                new[j][0][b], new[j][1][b] = pr[0][b], pr[1][b]
+                new[j][2][b] = pr[3][b, l]
+                for tt, tokens in enumerate(pr[5]):
+                    new[j][3][tt][b] = tokens[b]
+                new[j][3][-1][b] = pr[3][b, l]
+                new[j][4][b] = pr[4][b] - pr[2][b, l]
+        beams = new
+    return torch.stack(beams[0][3], 1), beams[0][4]
+
+
 def decoder_greedy(P, prefix, cell, init, first, T, mask_id=3):
     """Greedy branch of Decoder.forward (CV/Modules/decoder.py:176-201; vae_couple.py:173-201), eval mode:
     h_0 from the prefix step on [init, init]; then T steps of [emb(y_{t-1}), init] -> cell -> tanh(W_c h)

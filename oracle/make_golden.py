@@ -530,6 +530,15 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         out['greedy/latents'], out['greedy/go'] = lat.numpy(), go1.numpy()
         out['greedy/ids'] = np.asarray([[int(t.item()) for t in srow] for srow in sents_g], dtype=np.int64)
         meta['greedy_steps'] = int(out['greedy/ids'].shape[1])
+        # ---- beam branch (8f.3): same latents with Decoder.beam_size = 3 (an instance attribute read in
+        # forward; every shipped config has 1).  GRU only: the branch indexes the state as one tensor.
+        if cell == 'gru':
+            ae.Decoder.beam_size = 3
+            with torch.no_grad():
+                sents_b = ae.decode_from(lat, go1)
+            ae.Decoder.beam_size = 1
+            out['beam/ids'] = np.asarray([[int(t.item()) for t in srow] for srow in sents_b], dtype=np.int64)
+            meta['beam_size'] = 3
     else:
         sd_np('eval/')
 

@@ -166,6 +166,53 @@ def test_greedy_decode_vs_oracle_ptb_shape(dev, cell):
     assert n_diff == 0, '%d sentences differ from the fp64 oracle' % n_diff
 
 
+@pytest.mark.parametrize('name', [n for n in names('text_') if 'beam/ids' in Golden(n)])
+def test_beam_decode_matches_reference(dev, name):
+    """8f.3: the beam branch with the reference's Decoder.beam_size = 3 on the recorded latents: ids of
+    beam 0 bit-exact, in the reference's return format."""
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    tr.model.Decoder.beam_size = m['beam_size']
+    lat, go = g.t('greedy/latents').to(dev), g.t('greedy/go').to(dev)
+    ids = tr.model.decode_ids(lat, go)
+    assert ids.dtype == torch.int64 and torch.equal(ids.cpu(), g.t('beam/ids'))
+    sents = tr.model.decode_from(lat, go)
+    assert len(sents) == m['B'] and len(sents[0]) == m['max_len'] and tuple(sents[0][0].shape) == (1,)
+    assert int(sents[1][4]) == int(g.np('beam/ids')[1, 4])
+
+
+@pytest.mark.parametrize('cell,K', [('gru', 2), ('gru', 5), ('lstm', 3), ('lstm', 8)])
+def test_beam_decode_vs_oracle_ptb_shape(dev, cell, K):
+    """PTB shape, 40 steps x 24 sentences, K beams (K*B <= 256).  As for the greedy check a near-tie may
+    legitimately reorder candidates between fp32 and fp64; none is expected with these seeds.  The reported
+    cost of beam 0 agrees to 1e-4 relative."""
+    from cvae_amd import data, harness, ops
+    s = dict(data.SHAPES['ptb'])
+    s['V'] = 3000
+    T = 40
+    hp = harness.HParams(model='vae-couple', cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'], max_len=T)
+    tr = harness.Trainer(hp, dev, seed=6)
+    tr.model.train(False)
+    B = 24
+    lat = torch.randn(B, s['Z'], generator=torch.Generator().manual_seed(10))
+    go = torch.full((B, 1), 1, dtype=torch.int64)
+    from cvae_amd.modules import to_init
+    with torch.no_grad():
+        init = to_init(tr.model._to_init_seq(), lat.to(dev))
+        tr.model.Decoder.beam_size = K
+        ids, cost = tr.model.Decoder.beam(init, go.to(dev), return_nll=True)
+    ids, cost = ids.cpu(), cost.cpu()
+    assert tuple(ids.shape) == (B, T) and not (ids == 3).any()
+    P = O.tie_aliases({k: v.detach().cpu().double() for k, v in tr.model.state_dict().items()})
+    with torch.no_grad():
+        ref, ref_cost = O.decoder_beam(P, 'Decoder.', cell, O.to_init(P, 'toInit.', lat.double()), go[:, 0], T, K)
+    n_diff = int((ids != ref).any(1).sum())
+    assert n_diff == 0, '%d sentences differ from the fp64 oracle' % n_diff
+    assert rel(cost, ref_cost) < LOSS_TOL
+
+
 VAES = [n for n in names() if '_dae_' not in n and '_lm_' not in n]   # fixtures with a posterior: IW-NLL, corpus loop, MI
 
 
