@@ -594,6 +594,15 @@ class _DialogBase(nn.Module):
         post_repr = ops.linear(post, self.PostRepr.weight, self.PostRepr.bias)
         return post, post_repr, torch.cat([resp, post], dim=1)
 
+    def sample_from_prior(self, post_bare, post_len, resp_go):
+        """CC/Modules/vae_couple.py:369-397 / vae.py:157-184: encode the post, z ~ prior network, decode
+        (greedy or beam in eval mode; the reference's list-of-lists return format)."""
+        post = self.PostEncoder.last_flat(post_bare, post_len, 'post_enc_drop')
+        post_repr = ops.linear(post, self.PostRepr.weight, self.PostRepr.bias)
+        _, z = self.PriorGaussian(post, _noise_name='eps_prior')
+        init = to_init(self._to_init_seq(), z) + post_repr
+        return self.Decoder(None, init, resp_go)
+
     def test_lm(self, post_bare, post_len, resp_go, resp_len, resp_bare, resp_eos, n_sample):
         """CC/Modules/vae_couple.py:274-364 -> (xent, nll, kl)."""
         with torch.no_grad():

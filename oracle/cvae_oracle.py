@@ -564,6 +564,20 @@ def decoder_beam(P, prefix, cell, init, first, T, K, mask_id=3):
     return torch.stack(beams[0][3], 1), beams[0][4]
 
 
+def dialog_sample_from_prior(P, model, cell, post_bare, post_len, resp_go, eps, T, K=1):
+    """sample_from_prior of the dialogue models (CC/Modules/vae_couple.py:369-397; vae.py:157-184), eval
+    mode: post encoder -> PostRepr; z = mu_p + sigma_p * eps from the prior network; init = toInit(z) +
+    post_repr; greedy (K = 1) or beam decode of T steps from resp_go[:, 0].  eps (B,Z) -> ids (B,T)."""
+    post = encoder(P, 'PostEncoder.', cell, post_bare, post_len)
+    post_repr = post @ P['PostRepr.weight'].t() + P['PostRepr.bias']
+    mu_p, sig_p, _ = gaussian(P, 'PriorGaussian.', post)
+    init_pre = 'toInit.' if is_couple(model) else 'Decoder.toInit.'
+    init = to_init(P, init_pre, mu_p + sig_p * eps) + post_repr
+    if K > 1:
+        return decoder_beam(P, 'Decoder.', cell, init, resp_go[:, 0], T, K)[0]
+    return decoder_greedy(P, 'Decoder.', cell, init, resp_go[:, 0], T)
+
+
 def decoder_greedy(P, prefix, cell, init, first, T, mask_id=3):
     """Greedy branch of Decoder.forward (CV/Modules/decoder.py:176-201; vae_couple.py:173-201), eval mode:
     h_0 from the prefix step on [init, init]; then T steps of [emb(y_{t-1}), init] -> cell -> tanh(W_c h)

@@ -541,6 +541,26 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             meta['beam_size'] = 3
     else:
         sd_np('eval/')
+        # ---- generation (8f.3): sample_from_prior on one val batch -- post encoder, z from the prior
+        # network (its eps recorded), greedy decode; and, GRU only, the beam branch with beam_size = 3 ----
+        ae.train(False)
+        post_bare, post_len, resp_bare, resp_go, resp_eos, resp_len = vb
+        m = int(post_len.max()); post_bare = post_bare[:, :m].contiguous()
+        out['gen/post_bare'], out['gen/post_len'], out['gen/resp_go'] = post_bare.numpy(), post_len.numpy(), resp_go.numpy()
+        for tag, K in (('greedy', 1), ('beam', 3)):
+            if K > 1 and cell != 'gru':
+                continue
+            rec['noise'].clear()
+            ae.Decoder.beam_size = K
+            with torch.no_grad():
+                preds = ae.sample_from_prior(post_bare=post_bare, post_len=post_len, resp_go=resp_go)
+            ae.Decoder.beam_size = 1
+            eps = [t for kind, t in rec['noise'] if kind == 'eps']
+            assert len(eps) == 1 and tuple(eps[0].shape) == (1, post_bare.shape[0], shp['Z'])
+            out['gen/%s_eps' % tag] = eps[0].numpy()
+            out['gen/%s_ids' % tag] = np.asarray([[int(t.item()) for t in srow] for srow in preds], dtype=np.int64)
+        meta['gen_steps'] = int(out['gen/greedy_ids'].shape[1])
+        meta['beam_size'] = 3
 
     finish()
 

@@ -213,6 +213,34 @@ def test_beam_decode_vs_oracle_ptb_shape(dev, cell, K):
     assert rel(cost, ref_cost) < LOSS_TOL
 
 
+@pytest.mark.parametrize('name', [n for n in names('dialog_') if 'gen/greedy_ids' in Golden(n)])
+def test_dialog_sample_from_prior_matches_reference(dev, name):
+    """8f.3, dialogue tree: sample_from_prior with the recorded prior noise -> the reference's ids (greedy;
+    beam_size = 3 on the GRU fixtures), bit-exact, in its list-of-lists format."""
+    from cvae_amd import modules
+    g = Golden(name)
+    m = g.meta
+    tr = make_trainer(g, dev, 'eval/')
+    tr.model.train(False)
+    args = dict(post_bare=g.t('gen/post_bare').to(dev), post_len=g.t('gen/post_len').to(dev),
+                resp_go=g.t('gen/resp_go').to(dev))
+    try:
+        for tag, K in (('greedy', 1), ('beam', m['beam_size'])):
+            if 'gen/%s_ids' % tag not in g:
+                continue
+            modules.set_noise_source(modules.ReplayNoise({'eps_prior': [g.t('gen/%s_eps' % tag)]}))
+            tr.model.Decoder.beam_size = K
+            with torch.no_grad():
+                sents = tr.model.sample_from_prior(**args)
+            want = g.np('gen/%s_ids' % tag)
+            assert len(sents) == want.shape[0] and len(sents[0]) == want.shape[1] and tuple(sents[0][0].shape) == (1,)
+            got = np.asarray([[int(t) for t in row] for row in sents])
+            assert np.array_equal(got, want), tag
+    finally:
+        tr.model.Decoder.beam_size = 1
+        modules.set_noise_source(None)
+
+
 VAES = [n for n in names() if '_dae_' not in n and '_lm_' not in n]   # fixtures with a posterior: IW-NLL, corpus loop, MI
 
 
