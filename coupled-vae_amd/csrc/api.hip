@@ -913,6 +913,13 @@ int cvae_kl_backward(const float* mu, const float* sigma, const float* mu_p, con
   CVAE_REQUIRE(mu && sigma && gkl && dmu && dsigma, "kl_backward: null operand");
   return launch_kl_bwd(mu, sigma, mu_p, sigma_p, gkl, B, Z, dmu, dsigma, dmu_p, dsigma_p, S(stream));
 }
+int cvae_loss_assemble(int n, int B, const float* const* terms, const float* host_coef, float* out, void* stream) {
+  return launch_loss_assemble(n, B, terms, host_coef, out, S(stream));
+}
+int cvae_loss_assemble_backward(int n, int B, const float* gtot, const float* host_coef, float* const* dterms,
+                                void* stream) {
+  return launch_loss_assemble_bwd(n, B, gtot, host_coef, dterms, S(stream));
+}
 int cvae_kl_fb_forward(const float* mu, const float* sigma, int B, int Z, float floor, float* kl, void* stream) {
   CVAE_REQUIRE(mu && sigma && kl, "kl_fb_forward: null operand");
   return launch_kl_fb_fwd(mu, sigma, B, Z, floor, kl, S(stream));

@@ -357,6 +357,58 @@ int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, 
   return 0;
 }
 
+// ---- a11: loss assembly (CV/Experiment.py:753-757): batch means of up to four per-sentence terms and their
+// weighted sum, in one launch (the torch expression is ~20 tiny kernels forward and ~10 backward).
+struct LossTerms { const float* t[4]; float* d[4]; float coef[4]; };
+__global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms a, int n, int B, float* __restrict__ out) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float tot = 0.f;
+  for (int i = 0; i < n; ++i) {
+    float s = 0.f;
+    for (int b = tid; b < B; b += 256) s += a.t[i][b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[i][wave] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 0; i < n; ++i) {
+      const float m = (red[i][0] + red[i][1] + red[i][2] + red[i][3]) / (float)B;
+      out[1 + i] = m;
+      tot += a.coef[i] * m;
+    }
+    out[0] = tot;
+  }
+}
+__global__ void loss_assemble_bwd_kernel(LossTerms a, int n, int B, const float* __restrict__ gtot) {
+  IDX1D((long)n * B);
+  const int i = (int)(idx / B), b = (int)(idx % B);
+  a.d[i][b] = gtot[0] * a.coef[i] / (float)B;
+}
+int launch_loss_assemble(int n, int B, const float* const* terms, const float* coef, float* out, hipStream_t s) {
+  CVAE_REQUIRE(n >= 1 && n <= 4 && B > 0 && terms && coef && out, "loss_assemble: bad arguments (n=%d)", n);
+  LossTerms a = {};
+  for (int i = 0; i < n; ++i) {
+    CVAE_REQUIRE(terms[i], "loss_assemble: null term %d", i);
+    a.t[i] = terms[i]; a.coef[i] = coef[i];
+  }
+  hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, s, a, n, B, out);
+  CVAE_LAUNCH_CHECK("loss_assemble_kernel");
+  return 0;
+}
+int launch_loss_assemble_bwd(int n, int B, const float* gtot, const float* coef, float* const* dterms, hipStream_t s) {
+  CVAE_REQUIRE(n >= 1 && n <= 4 && B > 0 && gtot && coef && dterms, "loss_assemble_backward: bad arguments (n=%d)", n);
+  LossTerms a = {};
+  for (int i = 0; i < n; ++i) {
+    CVAE_REQUIRE(dterms[i], "loss_assemble_backward: null gradient %d", i);
+    a.d[i] = dterms[i]; a.coef[i] = coef[i];
+  }
+  hipLaunchKernelGGL(loss_assemble_bwd_kernel, GRID1D((long)n * B), 0, s, a, n, B, gtot);
+  CVAE_LAUNCH_CHECK("loss_assemble_bwd_kernel");
+  return 0;
+}
+
 // ---- f3: beam branch of Decoder.forward (CV/Modules/decoder.py:114-168; vae_couple.py:122-172) -----------
 // Per row: log_softmax over V with entry `mask_id` at -inf (decoder.py:138-142), then the K largest
 // entries in descending order (torch.topk, decoder.py:143; ties go to the lower index here).  One block

@@ -10,6 +10,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcvae_hip.so')
+if os.environ.get('CVAE_HIP_LIB'):        # diagnostics: an experimental build of the same library (scripts/build_variant.sh)
+    LIB_PATH = os.environ['CVAE_HIP_LIB']
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -45,6 +47,8 @@ SIGNATURES = {
     'cvae_decoder_greedy_scratch': [I, I, I, I, I, L],
     'cvae_decoder_greedy': [I, I, I, I, I, L, P, P, P, P, P, P, I, P, P, P],
     'cvae_decoder_beam_scratch': [I, I, I, I, I, I, L],
+    'cvae_loss_assemble': [I, I, P, P, P, P],
+    'cvae_loss_assemble_backward': [I, I, P, P, P, P],
     'cvae_decoder_beam': [I, I, I, I, I, I, L, P, P, P, P, P, P, I, P, P, P, P],
     'cvae_decoder_forward_n': [I, I, I, I, I, I, L] + [P] * 14,
     'cvae_decoder_backward_n': [I, I, I, I, I, I, L] + [P] * 16,

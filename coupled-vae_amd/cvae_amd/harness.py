@@ -179,14 +179,19 @@ class Trainer(object):
                 kl = ops.kl_free_bits(post.loc, post.scale, hp.lambda_fb / hp.Z)
             else:
                 kl = ops.kl_div(post.loc, post.scale)
-        res = {'seq': m.criterionSeq(logits, eos, keep_batch=True).mean(0), 'kl': kl.mean(0)}
+        # seq + lambda_KL * kl [+ lambda_seq_couple * seq_c + lambda_couple * couple], each a batch mean
+        # (Experiment.py:753-757): one launch for the means and the total (ops.loss_assemble)
         lam = lambda_kl(self.iter_num, hp)
-        tot = res['seq'] + lam * res['kl']
+        names, coef = ['seq', 'kl'], [1.0, lam]
+        terms = [m.criterionSeq(logits, eos, keep_batch=True), kl]
         if hp.is_couple():
-            res['seq_c'] = m.criterionSeq(logits_c, eos, keep_batch=True).mean(0)
-            res['couple'] = ops.couple_loss(init, init_c, hp.Z, hp.euclidean_dist).mean(0)
-            tot = tot + res['seq_c'] * hp.lambda_seq_couple + hp.lambda_couple * res['couple']
-        res['tot'] = tot
+            names += ['seq_c', 'couple']
+            coef += [hp.lambda_seq_couple, hp.lambda_couple]
+            terms += [m.criterionSeq(logits_c, eos, keep_batch=True),
+                      ops.couple_loss(init, init_c, hp.Z, hp.euclidean_dist)]
+        tot, means = ops.loss_assemble(terms, coef)
+        res = {nm: means[i] for i, nm in enumerate(names)}
+        res['tot'] = tot.view(())
         res['lambda_kl'] = lam
         return res
 

@@ -23,10 +23,21 @@ class NoiseSource(object):
     device generator in exactly the order and shapes the reference does (SURVEY 8a 'RNG draw
     order'); tests replace it with a replay of recorded tensors."""
 
+    _ones = {}                                   # device -> flat buffer of ones (input of the fused dropout kernel)
+
     def dropout_mask(self, shape, p, device, name):
+        """Mask with values {0, 1/(1-p)}: one fused dropout kernel over a cached buffer of ones (what
+        nn.Dropout itself launches in the reference), instead of fill + bernoulli + scale."""
         if p == 0.0:
             return None
-        return torch.bernoulli(torch.full(shape, 1.0 - p, dtype=torch.float32, device=device)) / (1.0 - p)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        buf = self._ones.get(device)
+        if buf is None or buf.numel() < n:
+            buf = torch.ones(max(n, 1 << 22), dtype=torch.float32, device=device)
+            NoiseSource._ones[device] = buf
+        return torch.nn.functional.dropout(buf[:n].view(shape), p, True)
 
     def normal(self, shape, device, name):
         return torch.empty(shape, dtype=torch.float32, device=device).normal_()

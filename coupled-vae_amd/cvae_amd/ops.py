@@ -3,6 +3,8 @@
 torch is plumbing here: it owns device memory, the stream and the autograd tape; every
 number is produced by libcvae_hip kernels.  All tensors are fp32 / int64 on the GPU.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -540,6 +542,38 @@ def logits_bt(final, W, b):
     tmp, out = _f((T * B, V), final), _f((B, T, V), final)
     call('cvae_logits', ptr(final), ptr(W), ptr(b), T, B, E, V, ptr(tmp), ptr(out), stream())
     return out
+
+
+class LossAssembleFn(torch.autograd.Function):
+    """tot = sum_i coef[i] * mean(term_i) and the means themselves (CV/Experiment.py:753-757), one launch.
+    -> (tot (1,), means (n,)); only tot carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, coef, *terms):
+        terms = [_c(t) for t in terms]
+        n, B = len(terms), terms[0].shape[0]
+        assert all(t.shape == (B,) for t in terms)
+        out = _f((n + 1,), terms[0])
+        carr = (ctypes.c_float * n)(*[float(c) for c in coef])
+        tarr = ptr_array(terms)
+        call('cvae_loss_assemble', n, B, tarr, carr, ptr(out), stream())
+        ctx.coef, ctx.n, ctx.B, ctx.like = carr, n, B, terms[0]
+        tot, means = out[:1], out[1:]
+        ctx.mark_non_differentiable(means)
+        return tot, means
+
+    @staticmethod
+    def backward(ctx, gtot, _gmeans):
+        gtot = _c(gtot)
+        d = [_f((ctx.B,), ctx.like) for _ in range(ctx.n)]
+        darr = ptr_array(d)
+        call('cvae_loss_assemble_backward', ctx.n, ctx.B, ptr(gtot), ctx.coef, darr, stream())
+        return (None,) + tuple(d)
+
+
+def loss_assemble(terms, coef):
+    """terms: list of (B,) tensors, coef: python floats -> (tot (1,), means (n,))."""
+    return LossAssembleFn.apply(tuple(coef), *terms)
 
 
 # --------------------------------------------------------------------------- latent space

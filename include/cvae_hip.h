@@ -240,6 +240,15 @@ int cvae_couple_forward(const float* init, const float* init_c, int B, int E, in
 int cvae_couple_backward(const float* init, const float* init_c, const float* d, const float* gloss, int B,
                          int E, int Z, int euclid, float* dinit, void* stream);
 
+/* ---- a11: loss assembly (Experiment.py:753-757; CC Experiment.py:405-415): the batch means of n <= 4
+ * per-sentence terms (seq, kl, seq_couple, couple) and tot = sum_i coef[i] * mean(term_i), one launch.
+ * terms: host array of n device pointers [B]; host_coef: n host floats (1, lambda_KL, lambda_seq_couple,
+ * lambda_couple).  out[n+1] (device): out[0] = tot, out[1+i] = mean(term_i). */
+int cvae_loss_assemble(int n, int B, const float* const* terms, const float* host_coef, float* out, void* stream);
+/* gtot: device scalar upstream -> dterms[i][b] = gtot * coef[i] / B (overwritten). */
+int cvae_loss_assemble_backward(int n, int B, const float* gtot, const float* host_coef, float* const* dterms,
+                                void* stream);
+
 /* ---- a13/a14: importance_sampling tail (Modules/vae_couple.py:558-578; log_sum_exp
  * utils/utils.py:69-82).  z[K,B,Z], xent[K,B] = -log p(x|z), posterior (mu,sigma)[B,Z],
  * prior (mu_p,sigma_p)[B,Z] or NULL (standard normal) ->
