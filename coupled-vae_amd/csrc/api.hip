@@ -202,6 +202,10 @@ int cvae_linear_backward(const float* x, const float* W, const float* y, const f
                          int K, float* dx, float* dW, float* db, float* scratch, void* stream) {
   hipStream_t s = S(stream);
   CVAE_REQUIRE(x && W && dy && dW && db, "linear_backward: null operand");
+  if (linear_bwd_small_supported(M, N, K)) {           // training-batch heads: one launch for everything
+    CVAE_REQUIRE(act == ACT_NONE || y, "linear_backward: act needs y");
+    return launch_linear_bwd_small(M, N, K, act, x, W, y, dy, dx, dW, db, s);
+  }
   const float* dpre = dy;
   if (act != ACT_NONE) {
     CVAE_REQUIRE(y && scratch, "linear_backward: act needs y and scratch");

@@ -357,6 +357,147 @@ int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, 
   return 0;
 }
 
+// Backward of a small linear layer y = act(x W^T + b) with M <= 64 rows (the Gaussian heads, toInit,
+// PostRepr at training batch sizes: a5 / a6), in ONE launch instead of act_bwd + 2 GEMMs + zero + colsum:
+//   dpre = dy * act'(y) (recomputed by every block from y, dy);
+//   blocks [0, nA): dW[n-tile of 16][k-tile of 64] = dpre^T x, and db for the k-tile-0 blocks;
+//   blocks [nA, nA + nB): dx[:, k-tile of 16] = dpre W.
+// Plain fp32 FMAs: at most a few MFLOP, the cost is the launch.
+__device__ __forceinline__ float act_grad(int act, float y, float g) {
+  if (act == ACT_TANH) return g * (1.f - y * y);
+  if (act == ACT_RELU) return y > 0.f ? g : 0.f;
+  if (act == ACT_EXP) return g * y;
+  return g;
+}
+__global__ __launch_bounds__(256) void linear_bwd_small_kernel(int M, int N, int K, int act,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ y,
+                                                               const float* __restrict__ dy, float* __restrict__ dx,
+                                                               float* __restrict__ dW, float* __restrict__ db, int nA,
+                                                               int kt) {
+  __shared__ float sd[64][17];
+  __shared__ __attribute__((aligned(16))) float sb[64][68];      // x rows (dW blocks) / W rows (dx blocks: 16 used)
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nA) {
+    const int n0 = ((int)blockIdx.x / kt) * 16, k0 = ((int)blockIdx.x % kt) * 64;
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int m = i >> 4, n = n0 + (i & 15);
+      float v = 0.f;
+      if (m < M && n < N) v = act_grad(act, act ? y[(long)m * N + n] : 0.f, dy[(long)m * N + n]);
+      sd[m][i & 15] = v;
+    }
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int m = i >> 6, k = k0 + (i & 63);
+      sb[m][i & 63] = (m < M && k < K) ? x[(long)m * K + k] : 0.f;
+    }
+    __syncthreads();
+    const int tn = tid >> 4, tk = (tid & 15) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < M; ++m) {
+      const float d = sd[m][tn];
+      const float4 xv = *reinterpret_cast<const float4*>(&sb[m][tk]);
+      acc[0] += d * xv.x; acc[1] += d * xv.y; acc[2] += d * xv.z; acc[3] += d * xv.w;
+    }
+    if (n0 + tn < N)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + tk + j < K) dW[(long)(n0 + tn) * K + k0 + tk + j] = acc[j];
+    if (k0 == 0 && tid < 16 && n0 + tid < N) {
+      float sum = 0.f;
+      for (int m = 0; m < M; ++m) sum += sd[m][tid];
+      db[n0 + tid] = sum;
+    }
+  } else {
+    // dx: all M rows x 16 columns per block (fp32 FMAs issue at 4 cycles each and a block has one wave
+    // per SIMD: narrow column tiles spread the N-long dot products over more CUs); N is walked in chunks
+    // of 64 whose operands are fetched into registers one chunk ahead
+    const int k0 = ((int)blockIdx.x - nA) * 16;
+    const int g = tid >> 4, tk = tid & 15;                       // rows 4g .. 4g+3, column k0 + tk
+    __shared__ __attribute__((aligned(16))) float sdd[64][68];   // dpre chunk [64 rows][64 n]
+    float (*sdw)[68] = sb;                                       // W chunk [64 n][16 k]
+    const float* yp = act ? y : dy;                              // act == 0: the value is not used
+    float yv[16], gv[16], pd[16], pw[4];
+    auto fetch = [&](int n0) {
+      // unconditional loads from clamped addresses, selected afterwards: all loads in flight together
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = tid + 256 * j;
+        const int m = i >> 6, n = n0 + (i & 63);
+        const long o = (long)min(m, M - 1) * N + min(n, N - 1);
+        yv[j] = yp[o]; gv[j] = dy[o];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j;
+        const int nw = n0 + (i >> 4), k = k0 + (i & 15);
+        pw[j] = W[(long)min(nw, N - 1) * K + min(k, K - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = tid + 256 * j;
+        const int m = i >> 6, n = n0 + (i & 63);
+        pd[j] = (m < M && n < N) ? act_grad(act, yv[j], gv[j]) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j;
+        const int nw = n0 + (i >> 4), k = k0 + (i & 15);
+        pw[j] = (nw < N && k < K) ? pw[j] : 0.f;
+      }
+    };
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = tid + 256 * j;
+        sdd[i >> 6][i & 63] = pd[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j;
+        sdw[i >> 4][i & 15] = pw[j];
+      }
+      __syncthreads();
+      if (n0 + 64 < N) fetch(n0 + 64);
+      if (4 * g < M) {
+        // the chunk is zero-padded to 64: constant trip count, reads batched ahead of the FMAs
+#pragma unroll 4
+        for (int nn = 0; nn < 64; nn += 4) {
+          float wv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wv[e] = sdw[nn + e][tk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 d = *reinterpret_cast<const float4*>(&sdd[4 * g + r][nn]);
+            acc[r] += d.x * wv[0] + d.y * wv[1] + d.z * wv[2] + d.w * wv[3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g + r < M && k0 + tk < K) dx[(long)(4 * g + r) * K + k0 + tk] = acc[r];
+  }
+}
+bool linear_bwd_small_supported(int M, int N, int K) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CVAE_FUSED_SMALL_LINEAR"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && M >= 1 && M <= 64 && N >= 1 && K >= 1 && (long)N * K <= 1024L * 1024;
+}
+int launch_linear_bwd_small(int M, int N, int K, int act, const float* x, const float* W, const float* y,
+                            const float* dy, float* dx, float* dW, float* db, hipStream_t s) {
+  CVAE_REQUIRE(linear_bwd_small_supported(M, N, K), "linear_bwd_small: M=%d N=%d K=%d not supported", M, N, K);
+  CVAE_REQUIRE(act == ACT_NONE || y, "linear_bwd_small: act needs y");
+  const int kt = (K + 63) / 64, nA = ((N + 15) / 16) * kt, nB = dx ? (K + 15) / 16 : 0;
+  hipLaunchKernelGGL(linear_bwd_small_kernel, dim3(nA + nB), dim3(256), 0, s, M, N, K, act, x, W, y, dy, dx, dW, db,
+                     nA, kt);
+  CVAE_LAUNCH_CHECK("linear_bwd_small_kernel");
+  return 0;
+}
+
 // ---- a11: loss assembly (CV/Experiment.py:753-757): batch means of up to four per-sentence terms and their
 // weighted sum, in one launch (the torch expression is ~20 tiny kernels forward and ~10 backward).
 struct LossTerms { const float* t[4]; float* d[4]; float coef[4]; };

@@ -22,6 +22,9 @@ int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* 
                      hipStream_t s);
 int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s);
 int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s);
+bool linear_bwd_small_supported(int M, int N, int K);
+int launch_linear_bwd_small(int M, int N, int K, int act, const float* x, const float* W, const float* y,
+                            const float* dy, float* dx, float* dW, float* db, hipStream_t s);
 int launch_loss_assemble(int n, int B, const float* const* terms, const float* coef, float* out, hipStream_t s);
 int launch_loss_assemble_bwd(int n, int B, const float* gtot, const float* coef, float* const* dterms, hipStream_t s);
 int launch_logsoftmax_topk(int R, int V, int K, const float* logits, long ld, int mask_id, float* lv, int* li,

@@ -111,6 +111,29 @@ def test_pack_batch_and_sort_bit_exact(dev):
         assert s.tolist() == s_ref and r.tolist() == r_ref
 
 
+@pytest.mark.parametrize('M,N,K,act', [(32, 32, 512, 0), (32, 32, 512, 3), (32, 200, 32, 2), (32, 200, 200, 0),
+                                        (5, 16, 4, 2), (64, 77, 131, 1), (1, 1, 1, 0), (33, 513, 70, 3),
+                                        (100, 200, 32, 2), (65, 32, 512, 3)])
+def test_linear_forward_backward(dev, M, N, K, act):
+    """y = act(x W^T + b) and its backward (a5 / a6 heads): M <= 64 takes the one-launch backward
+    (linear_bwd_small_kernel), larger M the GEMM path; both against fp64 torch."""
+    from cvae_amd import ops
+    x, W, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.3, seed=2), rnd(N, dev=dev, seed=3)
+    g = rnd(M, N, dev=dev, seed=4)
+    f = {0: lambda t: t, 1: torch.tanh, 2: torch.relu, 3: torch.exp}[act]
+    xr, Wr, br = (t.detach().double().cpu().requires_grad_(True) for t in (x, W, b))
+    ref = f(xr @ Wr.t() + br)
+    (ref * g.double().cpu()).sum().backward()
+    for need_dx in (True, False):
+        xd, Wd, bd = x.clone().requires_grad_(need_dx), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        got = ops.linear(xd, Wd, bd, act)
+        assert rel(got, ref) < 2e-5
+        (got * g).sum().backward()
+        assert rel(Wd.grad, Wr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
+        if need_dx:
+            assert rel(xd.grad, xr.grad) < 2e-5
+
+
 def _rnn_params(cell, inp, hid, bi, seed):
     G = 3 if cell == 'gru' else 4
     g = torch.Generator().manual_seed(seed)
