@@ -444,11 +444,13 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
                             float* dX, float* dW, float* db, float* ws, hipStream_t s) {
   CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && R > 0 && TR % R == 0 && N % TR == 0 && N < (1L << 31),
                "ce_backward: bad shape");
-  CVAE_TRY(launch_zero(dW, (long)V * E, s));
-  CVAE_TRY(launch_zero(db, V, s));
-  if (N == 0) return 0;
+  ZeroBatch zb(s);
+  zb.add(dW, (long)V * E);
+  zb.add(db, V);
+  if (N == 0) return zb.flush();
   CVAE_REQUIRE(X && W && bias && tgt && lse && gsent && dX && dW && db && ws, "ce_backward: null operand");
-  CVAE_TRY(launch_zero(dX, N * E, s));
+  zb.add(dX, N * E);
+  CVAE_TRY(zb.flush());
   int* rows = reinterpret_cast<int*>(ws);
   int* counts = rows + N;
   int* nlive = counts + ce_counts_slots(N) - 4;

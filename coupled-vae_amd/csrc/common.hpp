@@ -208,7 +208,9 @@ int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const 
 // rnn_persist.hip: all T steps of up to four lock-stepped sequences in one launch (R <= 32)
 bool rnn_persist_supported(int cell, int T, int R, int H, int ns);
 bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns);
-int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s);    // initial slots already set
+struct ZeroBatch;
+// initial slots already set or queued on zb (flushed here together with the flag words)
+int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb = nullptr);
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s);
 int persist_status_and_clear();
 

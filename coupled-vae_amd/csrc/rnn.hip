@@ -11,6 +11,7 @@
 // timesteps at once, done by the caller (api.hip).
 // Packed sequences (encoder) are handled by masking: a row is updated only while t < len.
 #include "common.hpp"
+#include "misc.hpp"
 #include "cell_math.hpp"
 
 namespace cvae {
@@ -76,15 +77,16 @@ static int rnn_forward_check(const RnnFwd& a) {
   return 0;
 }
 
-static int rnn_forward_init(const RnnFwd& a, hipStream_t s) {
+// zero initial states are queued on `zb` (flushed by the caller: one launch for all sequences)
+static int rnn_forward_init(const RnnFwd& a, hipStream_t s, ZeroBatch& zb) {
   const long RH = (long)a.R * a.H;
   const int init_slot = a.reverse ? a.T : 0;
   if (a.init_in_place) return 0;
   if (a.h0) CVAE_TRY(launch_copy(a.hs + init_slot * RH, a.h0, RH, s));
-  else CVAE_TRY(launch_zero(a.hs + init_slot * RH, RH, s));
+  else zb.add(a.hs + init_slot * RH, RH);
   if (a.cell == CELL_LSTM) {
     if (a.c0) CVAE_TRY(launch_copy(a.cs + init_slot * RH, a.c0, RH, s));
-    else CVAE_TRY(launch_zero(a.cs + init_slot * RH, RH, s));
+    else zb.add(a.cs + init_slot * RH, RH);
   }
   return 0;
 }
@@ -141,13 +143,15 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
 
 int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
   CVAE_REQUIRE(ns >= 1 && ns <= SKINNY_MAX_BATCH, "rnn_forward: %d sequences (max %d)", ns, SKINNY_MAX_BATCH);
+  ZeroBatch zb(s);
   for (int q = 0; q < ns; ++q) {
     CVAE_TRY(rnn_forward_check(a[q]));
     CVAE_REQUIRE(a[q].cell == a[0].cell && a[q].T == a[0].T && a[q].R == a[0].R && a[q].H == a[0].H,
                  "rnn_forward: lock-step sequences differ in shape");
-    CVAE_TRY(rnn_forward_init(a[q], s));
+    CVAE_TRY(rnn_forward_init(a[q], s, zb));
   }
   if (a[0].R > SKINNY_MAX_ROWS) {
+    CVAE_TRY(zb.flush());
     for (int q = 0; q < ns; ++q) CVAE_TRY(rnn_forward_large(a[q], s));
     return 0;
   }
@@ -155,7 +159,9 @@ int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
   for (int q = 0; q < ns; ++q)
     aligned = aligned && aligned16(a[q].hs) && (!a[q].cs || aligned16(a[q].cs)) &&
               (!a[q].gates || aligned16(a[q].gates)) && aligned16(a[q].W_hh);
-  if (aligned && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns)) return launch_rnn_forward_persist(a, ns, s);
+  if (aligned && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns))
+    return launch_rnn_forward_persist(a, ns, s, &zb);      // its flag words join the same zero launch
+  CVAE_TRY(zb.flush());
   SkinnyArgs k[SKINNY_MAX_BATCH];
   for (int i = 0; i < a[0].T; ++i) {
     for (int q = 0; q < ns; ++q) rnn_forward_step_args(a[q], i, k[q]);

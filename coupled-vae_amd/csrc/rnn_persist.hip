@@ -559,10 +559,15 @@ bool rnn_persist_supported(int cell, int T, int R, int H, int ns) {
   return H / P_HU <= P_MAXB && (H / P_HU) * ns <= cu_count();
 }
 
-int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s) {
+int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb) {
   unsigned* sync = nullptr;
   CVAE_TRY(persist_sync(&sync));
-  CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
+  if (zb) {
+    zb->add(reinterpret_cast<float*>(sync), P_FLAG_WORDS);
+    CVAE_TRY(zb->flush());
+  } else {
+    CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
+  }
   PFwdArgs p = {};
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
   p.nw = 0;
