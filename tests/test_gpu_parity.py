@@ -354,17 +354,65 @@ def test_train_step_vs_oracle_full_shape(dev, model, cell, shape):
     """PTB / Switchboard shapes (V=10k, E=200, H=128, B=32): losses and every gradient vs
     the oracle (fp32 CPU) with the same weights, batch and noise; V shrunk to 2000 so the
     CPU oracle stays in seconds."""
-    from cvae_amd import modules, data, harness
+    from cvae_amd import data
     s = dict(data.SHAPES[shape])
     s['V'] = 2000
+    B = 32
+    sents = data.synthetic_sentences(2 * B, s['V'], s['mu'], s['sigma'], 40, seed=5)
+    _train_step_vs_oracle(dev, model, cell, s, sents[:B], sents[B:])
+
+
+def _edge_sentences(case, V):
+    rs = np.random.RandomState(11)
+    mk = lambda n: rs.randint(4, V, size=n).astype(np.int64)
+    if case == 'single':            # one sentence
+        return [mk(7)], [mk(3)]
+    if case == 'all_len1':          # every sentence one token: T = 2, L = 1
+        return [mk(1) for _ in range(32)], [mk(1) for _ in range(32)]
+    if case == 'equal':             # no ragged edge at all
+        return [mk(12) for _ in range(32)], [mk(9) for _ in range(32)]
+    if case == 'max_len':           # a sentence longer than max_len (cut at 200), one exactly 200, and one-token rows
+        return [mk(205), mk(1), mk(200), mk(3)], [mk(2), mk(200), mk(1), mk(230)]
+    if case == 'b33':               # one row more than the whole-sequence kernels take: per-step kernels
+        return [mk(int(n)) for n in rs.randint(1, 21, size=33)], [mk(int(n)) for n in rs.randint(1, 21, size=33)]
+    if case == 'b256':              # the largest batch the encoder / decoder entry points accept
+        return [mk(int(n)) for n in rs.randint(1, 7, size=256)], [mk(int(n)) for n in rs.randint(1, 7, size=256)]
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize('model,cell', [('vae-couple', 'lstm'), ('vae-couple', 'gru'), ('cvae-couple', 'gru')])
+@pytest.mark.parametrize('case', ['single', 'all_len1', 'equal', 'max_len', 'b33', 'b256'])
+def test_train_step_edge_batches(dev, model, cell, case):
+    """Degenerate and extreme batches through the whole training forward + backward against the oracle:
+    B = 1, one-token sentences, no ragged edge, truncation at max_len = 200 beside one-token rows,
+    B = 33 (falls off the whole-sequence kernels) and B = 256 (entry-point maximum)."""
+    s = dict(V=300, E=24, H=128 if case not in ('max_len', 'b256') else 32, Z=8)
+    a, b = _edge_sentences(case, s['V'])
+    _train_step_vs_oracle(dev, model, cell, s, a, b)
+
+
+def test_batch_larger_than_maximum_is_refused(dev):
+    """B = 257 must fail loudly at the boundary, not fall back."""
+    from cvae_amd import harness, _lib
+    hp = harness.HParams(model='vae', cell='gru', V=50, E=8, H=8, Z=4)
+    tr = harness.Trainer(hp, dev, seed=0)
+    rs = np.random.RandomState(0)
+    from cvae_amd import data
+    c = data.Corpus([rs.randint(4, 50, size=3).astype(np.int64) for _ in range(257)])
+    with pytest.raises(_lib.CvaeHipError):
+        tr.forward_backward(harness.text_batch(c, range(257), dev))
+
+
+def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2):
+    from cvae_amd import modules, data, harness
     hp = harness.HParams(model=model, cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'],
                          lambda_couple=2.0 if model.startswith('cvae') else 0.1)
     tr = harness.Trainer(hp, dev, seed=3)
     sd = tr.model.state_dict(keep_vars=True)
     P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in sd.items()})
     keys = list(sd.keys())
-    B = 32
-    sents = data.synthetic_sentences(2 * B, s['V'], s['mu'], s['sigma'], 40, seed=5)
+    B = len(sents1)
+    sents = list(sents1) + list(sents2)
     c1, c2 = data.Corpus(sents[:B]), data.Corpus(sents[B:])
     if hp.is_dialog():
         batch = harness.dialog_batch(c1, c2, range(B), dev)
