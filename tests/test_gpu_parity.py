@@ -500,6 +500,38 @@ def test_iw_nll_vs_oracle_and_row_chunking(dev, cell):
             assert rel(a, b) < 1e-6
 
 
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+@pytest.mark.parametrize('case,K', [('single', 4), ('single', 300), ('all_len1', 10), ('equal', 10), ('max_len', 2),
+                                    ('max_len', 70), ('b33', 8)])
+def test_iw_nll_edge_batches(dev, cell, case, K):
+    """IW-NLL on degenerate / extreme evaluation batches against the oracle: one sentence (K = 300 puts a
+    single sentence on the many-row layout), one-token sentences, equal lengths, a sentence at max_len
+    beside one-token ones (K = 70: 280 rows, sorted layout, most rows dead for 199 steps), B = 33."""
+    from cvae_amd import modules, data, harness
+    s = dict(V=300, E=24, H=32, Z=8)
+    sents, _ = _edge_sentences(case, s['V'])
+    B = len(sents)
+    hp = harness.HParams(model='vae-couple', cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'])
+    tr = harness.Trainer(hp, dev, seed=4)
+    c = data.Corpus(sents)
+    batch = harness.text_batch(c, range(B), dev, truncate=False)
+    eps = torch.randn(K, B, s['Z'], generator=torch.Generator().manual_seed(2))
+    P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    cb = {k: v.cpu() for k, v in batch.items()}
+    m = int(cb['len'].max())
+    cb_t = dict(bare=cb['bare'][:, :m], go=cb['go'][:, :m + 1], eos=cb['eos'][:, :m + 1], len=cb['len'])
+    with torch.no_grad():
+        xent, nll, kl, _ = O.iw_nll(P, 'vae-couple', cell, cb_t, eps)
+    tr.model.train(False)
+    modules.set_noise_source(modules.ReplayNoise({'iw_eps': _chunks(eps)}))
+    try:
+        got = tr.model.test_lm(bare=batch['bare'], sent_len=batch['len'], go=batch['go'], eos=batch['eos'], n_sample=K)
+    finally:
+        modules.set_noise_source(None)
+    assert rel(got[0], xent) < LOSS_TOL and rel(got[1], nll) < LOSS_TOL
+    assert float((got[2].cpu() - kl).abs().max()) < 5e-4 * float(kl.abs().max()) + 1e-5
+
+
 def test_train_step_with_vocab_not_multiple_of_four(dev):
     """PTB's vocabulary is 10002: the V-sized biases must not misalign the parameters packed after them
     (the whole-sequence recurrent kernels read weights with 16-byte loads).  One step vs the oracle."""
