@@ -314,19 +314,28 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
 //   4. publish part, destination-major: ex[dest block][this block][32 rows][4 units] (sc1 16-byte
 //      stores), drain, flag.  The destination reads one contiguous nb x 512 B run.
 // Two exchange buffers (step parity).  Deterministic: partials are summed in block order.
-template <int CELL>
+// HU = hidden units per block (4 or 8).  A block's traffic per step does not depend on HU (it publishes
+// its 32 x H partial and gathers 32 x H of others' partials either way), so the exchange volume of a
+// sequence is (H / HU) x 2 x 32 x H x 4 B per step: HU = 8 halves it (and the number of flags to poll) at
+// twice the -- small -- MFMA and cell work per block.
+template <int CELL, int HU>
 __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
-  constexpr int NC = P_HU * G;                       // live K of this block's slice (12 / 16)
-  extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[32][H + 4]  (aliased: red[32][32][4])
-  __shared__ __attribute__((aligned(16))) float dGl[32][16];       // dG of this block: [row][u*G + g]
+  constexpr int NC = HU * G;                         // live K of this block's slice (12 / 16 / 24 / 32)
+  constexpr int KS = (NC + 3) / 4;                   // MFMA K steps
+  constexpr int LDG = KS * 4 + 1;                    // dGl row stride: odd -> the fragment reads are conflict-free
+  constexpr int GPR = HU / 4;                        // 16-byte granules per (row, destination) piece
+  constexpr int PIECE = 32 * HU;                     // floats one block sends to one destination per step
+  constexpr int NGRP = P_THREADS / (32 * GPR);       // source groups after the gather's first pass
+  extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[32][H + 4]  (aliased: red[1024][4])
+  __shared__ float dGl[32][LDG];                                   // dG of this block: [row][u*G + g]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const PSeqB& q = p.q[blockIdx.y];
   const int H = p.H, R = p.R, T = p.T, nb = gridDim.x;
   const int GH = G * H, LDT = H + 4;
-  const int u0 = blockIdx.x * P_HU;
+  const int u0 = blockIdx.x * HU;
   const long RH = (long)R * H;
   float* tile = dyn;
   float* red = dyn;
@@ -335,27 +344,27 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float* dgh_base = q.dgh ? q.dgh : q.dgx;
-  // exchange: [parity][dest][src][32][4] floats
-  const long ex_par = (long)nb * nb * 128;
+  // exchange: [parity][dest][src][32][HU] floats
+  const long ex_par = (long)nb * nb * PIECE;
   const __amdgpu_buffer_rsrc_t rs_ex = make_rsrc(p.exch + (size_t)blockIdx.y * 2 * ex_par);
   if (tid == 0) s_abort = 0;
-  for (int i = tid; i < 32 * 16; i += P_THREADS) (&dGl[0][0])[i] = 0.f;
+  for (int i = tid; i < 32 * LDG; i += P_THREADS) (&dGl[0][0])[i] = 0.f;
 
   // W_hh[gate rows of U, :] as B fragments: wave w owns output column fragments w, w + 16, ...
   // (H / 16 fragments); fragment nf, MFMA step s: lane (n = l15, kq) holds W_hh[row(4s + kq)][16*nf + l15]
   const int nfr = H / 16;
-  float w[2][4];
+  float w[2][KS];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const int nf = wave + 16 * j, k = 4 * s + kq;
       w[j][s] = 0.f;
       if (nf < nfr && k < NC) w[j][s] = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
     }
 
-  const bool cellt = tid < 128;
-  const int crow = tid >> 2, cu = tid & 3, cn = u0 + cu;
+  const bool cellt = tid < 32 * HU;
+  const int crow = tid / HU, cu = tid % HU, cn = u0 + cu;
   const bool crv = cellt && crow < R;
   float dh_carry = 0.f, dc = 0.f;
   int64_t len = 0;
@@ -376,28 +385,31 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   int rb_prev = 0;                                      // bound of the partials published last
   __syncthreads();
 
+  // 16-byte granule gq of a block's 32 x H floats: (block d = gq / (32*GPR), row = (gq / GPR) % 32,
+  // part = gq % GPR); a thread's granules gq = tid + 1024 j share row and part (1024 % (32*GPR) == 0)
+  const int grow = (tid / GPR) & 31, gpart = tid % GPR;
+  const int ngran = 8 * H;                              // = nb * 32 * GPR
+
   // sum over all source blocks of their partial for (crow, cu); parity = buffer to read
   auto gather = [&](int parity, int bound) -> float {
-    const long base = (long)parity * ex_par + (long)blockIdx.x * nb * 128;
-    // piece p = src * 32 + row; this thread takes p = tid, tid + 1024, ...
+    const long base = (long)parity * ex_par + (long)blockIdx.x * nb * PIECE;
     f32x4v sum = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const int npieces = nb * 32;
     f32x4v v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      const int pc = tid + P_THREADS * j;
-      if (pc < npieces && (tid & 31) < bound) v[j] = ld16_sc1(rs_ex, base + (long)pc * 4);
+      const int gq = tid + P_THREADS * j;
+      if (gq < ngran && grow < bound) v[j] = ld16_sc1(rs_ex, base + (long)gq * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sum += v[j];
-    // red[group = tid >> 5][row = tid & 31][4]
+    // red[group = tid / (32*GPR)][row][part][4]
     *reinterpret_cast<f32x4v*>(red + (size_t)tid * 4) = sum;
     __syncthreads();
     float tot = 0.f;
     if (cellt) {
 #pragma unroll 8
-      for (int g = 0; g < 32; ++g) tot += red[((size_t)g * 32 + crow) * 4 + cu];
+      for (int g = 0; g < NGRP; ++g) tot += red[((size_t)(g * 32 + crow) * GPR + (cu >> 2)) * 4 + (cu & 3)];
     }
     __syncthreads();                                  // red is aliased with the product tile
     return tot;
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
       // A operand of the product: the h-side gradients
 #pragma unroll
       for (int g = 0; g < G; ++g) dGl[crow][cu * G + g] = (CELL == CELL_GRU) ? oh[g] : ox[g];
-      // global copies for the weight gradients: 16-byte stores per (row, gate)
+      // global copies for the weight gradients: 16-byte stores per (row, gate, 4 units)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         f32x4v vx, vh;
@@ -447,8 +459,8 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
           vx[d] = __shfl_down(ox[g], d, 64);
           if (CELL == CELL_GRU) vh[d] = __shfl_down(oh[g], d, 64);
         }
-        if (crv && cu == 0) {
-          const long o = ((long)t * R + crow) * GH + g * H + u0;
+        if (crv && (cu & 3) == 0) {
+          const long o = ((long)t * R + crow) * GH + g * H + cn;
           *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
           if (CELL == CELL_GRU) *reinterpret_cast<f32x4v*>(dgh_base + o) = vh;
           else if (q.dgx != dgh_base) *reinterpret_cast<f32x4v*>(dgh_base + o) = vx;
@@ -457,20 +469,20 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     }
     __syncthreads();
     P_STAMP(3);
-    // product: two 16-row fragments x this wave's column fragments, K = 16 (4 steps)
+    // product: two 16-row fragments x this wave's column fragments, K = NC (KS steps)
     {
-      float a[2][4];
+      float a[2][KS];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[f][s] = dGl[16 * f + l15][4 * s + kq];
+        for (int s = 0; s < KS; ++s) a[f][s] = dGl[16 * f + l15][4 * s + kq];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nf = wave + 16 * j;
         if (nf < nfr) {
           f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < KS; ++s) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], w[j][s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], w[j][s], acc1, 0, 0, 0);
           }
@@ -484,18 +496,18 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
       }
     }
     __syncthreads();
-    // publish, destination-major: piece (dest d, row r) = tile[r][4d .. 4d+3] -> ex[parity][d][me][r][0..3]
+    // publish, destination-major: granule (dest d, row r, part) = tile[r][HU*d + 4*part ..] ->
+    // ex[parity][d][me][r][4*part ..]
     {
-      const long wbase = (long)((T - i) & 1) * ex_par + (long)blockIdx.x * 128;
-      const int npieces = nb * 32;
+      const long wbase = (long)((T - i) & 1) * ex_par + (long)blockIdx.x * PIECE;
       rb_prev = row_bound(t);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int pc = tid + P_THREADS * j;
-        if (pc < npieces && (pc & 31) < rb_prev) {
-          const int d = pc >> 5, r = pc & 31;
-          const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + r * LDT + 4 * d);
-          st16_sc1(rs_ex, wbase + ((long)d * nb) * 128 + (long)r * 4, v);
+        const int gq = tid + P_THREADS * j;
+        if (gq < ngran && grow < rb_prev) {
+          const int d = gq / (32 * GPR);
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + grow * LDT + HU * d + 4 * gpart);
+          st16_sc1(rs_ex, wbase + ((long)d * nb) * PIECE + (long)grow * HU + 4 * gpart, v);
         }
       }
     }
@@ -625,9 +637,12 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
   p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
   const int G = a[0].cell == CELL_GRU ? 3 : 4;
-  const int nb = p.H / P_HU;
-  CVAE_REQUIRE(p.H % 16 == 0 && p.H / 16 <= 32, "rnn_backward_persist: H=%d", p.H);
-  CVAE_TRY(persist_exch((long)ns * 2 * nb * nb * 128, &p.exch));
+  static int hu_env = 0;                       // CVAE_PERSIST_BWD_HU=4: the 4-unit blocks (more, thinner blocks)
+  if (!hu_env) { const char* e = getenv("CVAE_PERSIST_BWD_HU"); hu_env = (e && atoi(e) == 4) ? 4 : 8; }
+  const int hu = (hu_env == 8 && p.H % 8 == 0) ? 8 : 4;
+  const int nb = p.H / hu;
+  CVAE_REQUIRE(p.H % 16 == 0 && p.H / 16 <= 32 && nb <= P_MAXB, "rnn_backward_persist: H=%d", p.H);
+  CVAE_TRY(persist_exch((long)ns * 2 * nb * nb * 32 * hu, &p.exch));
   for (int k = 0; k < ns; ++k) {
     const RnnBwd& r = a[k];
     float* dgh = r.dgh ? r.dgh : r.dgx;
@@ -648,15 +663,24 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   const dim3 grid(nb, ns), block(P_THREADS);
   static bool attr_set = false;
   if (!attr_set) {
-    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "persist bwd LDS attribute"));
-    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "persist bwd LDS attribute"));
+    const void* fns[4] = {reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 4>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 8>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 8>)};
+    for (const void* f : fns)
+      CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                         "persist bwd LDS attribute"));
     attr_set = true;
   }
   ProfScope prof(PK_RNN_PERSIST_BWD, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
-  if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_GRU>, grid, block, lds, s, p);
-  else hipLaunchKernelGGL(rnn_bwd_persist_kernel<CELL_LSTM>, grid, block, lds, s, p);
+  const bool gru = a[0].cell == CELL_GRU;
+  if (hu == 8) {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 8>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 8>), grid, block, lds, s, p);
+  } else {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 4>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 4>), grid, block, lds, s, p);
+  }
   CVAE_LAUNCH_CHECK("rnn_bwd_persist_kernel");
   return 0;
 }
