@@ -241,6 +241,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
     __syncthreads();
     P_STAMP(3);
 
+    float sv_c = 0.f, sv_g[4] = {0.f, 0.f, 0.f, 0.f};      // this step's c and gates, stored after the flag
     if (cellt) {
       float s[G];
 #pragma unroll
@@ -273,19 +274,32 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
         g0 = g1 = g2 = g3 = 0.f;
       }
       hprev = hnew; cprev = cnew;
-      // gather the 4 units of a row into the lane of unit 0: 16-byte stores
-      f32x4v hv, cv, gv[4];
-      hv[0] = hnew; cv[0] = cnew; gv[0][0] = g0; gv[1][0] = g1; gv[2][0] = g2; gv[3][0] = g3;
+      // gather the 4 units of a row into the lane of unit 0: 16-byte stores.  Only h is the hand-off
+      // payload: it goes out first and alone; c and the gates (saved for backward) are packed and
+      // stored AFTER the flag is raised, off the step's critical path (the next publish drains them).
+      f32x4v hv;
+      hv[0] = hnew;
+#pragma unroll
+      for (int d = 1; d < 4; ++d) hv[d] = __shfl_down(hnew, d, 64);
+      if (crv && cu == 0) st16_sc1(rs_hs, out_slot * RH + (long)crow * H + u0, hv);
+      sv_c = cnew; sv_g[0] = g0; sv_g[1] = g1; sv_g[2] = g2; sv_g[3] = g3;
+    }
+    P_STAMP(4);
+    publish(flg, (unsigned)(i + 1));
+    P_STAMP(5);
+    if (cellt) {
+      f32x4v cv, gv[4];
+      cv[0] = sv_c;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gv[g][0] = sv_g[g];
 #pragma unroll
       for (int d = 1; d < 4; ++d) {
-        hv[d] = __shfl_down(hnew, d, 64);
-        cv[d] = __shfl_down(cnew, d, 64);
-        gv[0][d] = __shfl_down(g0, d, 64); gv[1][d] = __shfl_down(g1, d, 64);
-        gv[2][d] = __shfl_down(g2, d, 64); gv[3][d] = __shfl_down(g3, d, 64);
+        cv[d] = __shfl_down(sv_c, d, 64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g][d] = __shfl_down(sv_g[g], d, 64);
       }
       if (crv && cu == 0) {
         const long o = (long)crow * H + u0;
-        st16_sc1(rs_hs, out_slot * RH + o, hv);                                   // the hand-off payload
         if (CELL == CELL_LSTM) *reinterpret_cast<f32x4v*>(q.cs + out_slot * RH + o) = cv;
         if (q.gates) {
           float* gp = q.gates + ((long)t * R + crow) * 4 * H + u0;
@@ -294,9 +308,6 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
         }
       }
     }
-    P_STAMP(4);
-    publish(flg, (unsigned)(i + 1));
-    P_STAMP(5);
   }
   if (stamp_on)
     for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
