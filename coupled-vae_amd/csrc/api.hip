@@ -520,6 +520,14 @@ int cvae_decoder_forward_sorted(int cell, int B, int K, int T, int E, int Hd, in
   f.hs = hs + RH; f.cs = cs ? cs + RH : nullptr;
   f.init_in_place = 1;
   CVAE_TRY(launch_rnn_forward(f, s));
+  // final_t = tanh(W_c h_t) for the live rows of every step: one batched launch (blockIdx.z = t)
+  if (T <= GEMM_MAX_BATCH) {
+    GemmDesc d = {};
+    d.transA = 0; d.transB = 1; d.N = E; d.K = Hd;
+    d.A = hs + 2 * RH; d.lda = Hd; d.B = W_c; d.ldb = Hd; d.C = final; d.ldc = E; d.bias = b_c; d.act = ACT_TANH;
+    d.nbatch = T; d.batchA = RH; d.batchC = (long)R * E; d.host_mbatch = live.data();
+    return launch_gemm(d, s);
+  }
   for (int t = 0; t < T; ++t)
     if (live[t] > 0)
       CVAE_TRY(linear_nt(hs + (t + 2) * RH, W_c, Hd, b_c, ACT_TANH, live[t], E, Hd, final + (long)t * R * E, s));

@@ -78,6 +78,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- internal launchers shared between translation units (all enqueue on `s`) ----------
+constexpr int GEMM_MAX_BATCH = 256;
 struct GemmDesc {
   int transA, transB;        // op(A) is MxK: transA=0 -> A[m*lda+k], 1 -> A[k*lda+m]
   int M, N, K;               // op(B) is KxN: transB=0 -> B[k*ldb+n], 1 -> B[n*ldb+k]
@@ -93,6 +94,9 @@ struct GemmDesc {
   // gradient.  Free when the product runs as gemm_wide with a spare tile column (a ones column in
   // the staged B tile); otherwise one extra pass over A.
   float* colsum_out;
+  // nbatch > 0 (plain A only): nbatch products sharing B; batch i reads A + i*batchA, writes C + i*batchC
+  // and has host_mbatch[i] rows (M is ignored).  One launch of the tiled kernel, blockIdx.z = batch.
+  int nbatch; long batchA, batchC; const int* host_mbatch;
   // Optional live-row list (device): the product only visits rows[0 .. *nlive) of the row dimension
   // that A shares with C (bound_dim 1: C = A B, rows of A and C; the caller has zeroed C) or with
   // B (bound_dim 2, transA: C = A^T B, rows of A and B).  Rows outside the list must be exactly

@@ -25,8 +25,9 @@ struct TiledArgs {
   const float* row_lse; const float* row_coef; const int64_t* row_tgt;   // ACT_CEGRAD
 };
 
+// zk / nz: index and count of the K ranges (split-K) this launch is divided into
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
+__device__ __forceinline__ void gemm_tiled_body(const TiledArgs& p, const int zk, const int nz) {
   // op(A) rows = m: stored [m][k] when !TA (k contiguous) ; op(B) "rows" = n: stored [n][k] when TB
   using LA = TileLoader<BM, !TA>;
   using LB = TileLoader<BN, TB>;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   LA la; LB lb;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int kbeg = zk * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
   la.load(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA, tid);
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
     for (int j = 0; j < NI; ++j) {
       const int n = n0 + wn0 + j * 32 + l31;
       if (n >= p.N) continue;
-      const float bv = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
+      const float bv = (p.bias && zk == 0) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (m < p.M) {
           float v = acc[i][j][r] + bv;
           float* c = p.C + (long)m * p.ldc + n;
-          if (gridDim.z > 1) {
+          if (nz > 1) {
             atomicAdd(c, v);          // split-K: C was zeroed (or holds the beta term) by the host
           } else {
             if (p.act == ACT_CEGRAD)  // d(loss)/d(logit) = coef * (softmax - onehot)
@@ -110,6 +111,53 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
         }
       }
     }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
+  gemm_tiled_body<BM, BN, TA, TB>(p, blockIdx.z, gridDim.z);
+}
+
+// Batch of products with one B: blockIdx.z = batch; A and C advance by a stride, the row count of
+// every batch comes with the launch (the IW-eval decoder: one slab of live rows per timestep).
+struct TiledBatch { long sA, sC; int m[GEMM_MAX_BATCH]; };
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_tiled_batched_kernel(TiledArgs p, TiledBatch b) {
+  p.M = b.m[blockIdx.z];
+  if ((int)blockIdx.y * BM >= p.M) return;
+  p.A += (long)blockIdx.z * b.sA;
+  p.C += (long)blockIdx.z * b.sC;
+  gemm_tiled_body<BM, BN, TA, TB>(p, 0, 1);
+}
+
+static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
+  CVAE_REQUIRE(d.nbatch >= 1 && d.nbatch <= GEMM_MAX_BATCH && d.host_mbatch, "gemm(batched): 1..%d batches", GEMM_MAX_BATCH);
+  CVAE_REQUIRE(!d.transA && d.act != ACT_CEGRAD && !d.colsum_out && !d.rows, "gemm(batched): unsupported form");
+  TiledArgs a = {};
+  a.A = d.A; a.B = d.B; a.C = d.C; a.bias = d.bias;
+  a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc;
+  a.N = d.N; a.K = d.K; a.act = d.act; a.beta = d.beta;
+  a.vecA = aligned16(d.A) && (d.lda % 4 == 0) && (d.batchA % 4 == 0);
+  a.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
+  a.kchunk = (d.K + BK - 1) / BK * BK;
+  TiledBatch b = {};
+  b.sA = d.batchA; b.sC = d.batchC;
+  int mmax = 0;
+  double rows = 0;
+  for (int i = 0; i < d.nbatch; ++i) {
+    CVAE_REQUIRE(d.host_mbatch[i] >= 0, "gemm(batched): negative row count");
+    b.m[i] = d.host_mbatch[i];
+    mmax = b.m[i] > mmax ? b.m[i] : mmax;
+    rows += b.m[i];
+  }
+  if (mmax == 0) return 0;
+  constexpr int BM = 128, BN = 128;
+  dim3 grid(cdiv(d.N, BN), cdiv(mmax, BM), d.nbatch);
+  ProfScope prof(PK_GEMM_TILED, s, 2.0 * rows * d.N * d.K);
+  if (d.transB) hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, b);
+  else hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a, b);
+  CVAE_LAUNCH_CHECK("gemm_tiled_batched");
+  return 0;
 }
 
 template <int BM, int BN>
@@ -153,6 +201,10 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
 
 int launch_gemm(const GemmDesc& d, hipStream_t s) {
   CVAE_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dimension");
+  if (d.nbatch > 0) {
+    CVAE_REQUIRE(d.A && d.B && d.C && d.K > 0 && d.N > 0, "gemm(batched): null operand or empty product");
+    return launch_tiled_batched(d, s);
+  }
   if (d.M == 0 || d.N == 0) return 0;
   CVAE_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
   CVAE_REQUIRE(d.act != ACT_CEGRAD || (d.row_lse && d.row_coef && d.row_tgt && !d.beta), "gemm: CE-grad epilogue operands missing");
