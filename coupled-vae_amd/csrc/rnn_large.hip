@@ -12,13 +12,20 @@
 //  * both operands are k-contiguous ([row][k]); LDS rows of BK + 4 floats make the b128 fragment
 //    reads conflict-free; lane (l31, lhi) reads k = 8q + 4*lhi + (0..3) of its row for A and B
 //    alike, i.e. both sides see the same permutation of k (v_mfma_f32_32x32x2_f32, 4 steps per read);
-//  * double-buffered LDS, one barrier per 32-wide K chunk, every global load a whole float4
+//  * double-buffered LDS, one barrier per RL_BK-wide K chunk (16: 354 us per 16 000-row step against 375 us
+//    with 32), every global load a whole float4
 //    (rows past the live prefix are clamped to a valid row; their results are not stored).
 #include "common.hpp"
 
 namespace cvae {
 
-constexpr int RL_BM = 128, RL_BU = 32, RL_BK = 32, RL_LD = RL_BK + 4;
+#ifndef RL_BK_
+#define RL_BK_ 16
+#endif
+#ifndef RL_OCC_
+#define RL_OCC_ 2
+#endif
+constexpr int RL_BM = 128, RL_BU = 32, RL_BK = RL_BK_, RL_LD = RL_BK + 4, RL_F4 = RL_BK / 4;   // RL_LD / 4 odd: conflict-free b128
 
 struct RnnLargeArgs {
   const float* h_prev; const float* c_prev; const float* W_hh; const float* b_hh;
@@ -28,7 +35,7 @@ struct RnnLargeArgs {
 };
 
 template <int CELL>
-__global__ __launch_bounds__(256, 2) void rnn_large_step_kernel(RnnLargeArgs p) {
+__global__ __launch_bounds__(256, RL_OCC_) void rnn_large_step_kernel(RnnLargeArgs p) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
   extern __shared__ __attribute__((aligned(16))) float rl_smem[];       // 2 x (A tile + B tile) = 72 KB (LSTM)
   float (*As)[RL_BM * RL_LD] = reinterpret_cast<float (*)[RL_BM * RL_LD]>(rl_smem);
@@ -43,10 +50,11 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_kernel(RnnLargeArgs p) 
   const int u0 = utile * RL_BU, m0 = rowtile * RL_BM;
   if (m0 >= p.live) return;
 
-  // staging: A 128 rows x 8 float4, B (G*32) rows x 8 float4; thread -> (row = idx >> 3, k4 = idx & 7)
+  // staging: A 128 rows x RL_F4 float4, B (G*32) rows x RL_F4 float4; thread -> (row = idx / RL_F4, k4 = idx % RL_F4)
   constexpr int NA = RL_BM * (RL_BK / 4) / 256;          // 4
-  constexpr int NB = G * RL_BU * (RL_BK / 4) / 256;      // 3 (GRU) / 4 (LSTM)
-  static_assert(NB * 256 == G * RL_BU * (RL_BK / 4), "B tile must divide over the block");
+  constexpr int NBT = G * RL_BU * (RL_BK / 4);           // float4 pieces of the B tile: 384 (GRU) / 512 (LSTM)
+  constexpr int NB = (NBT + 255) / 256;                  // 2; the GRU's second pass covers half the block
+  constexpr bool NB_EXACT = NB * 256 == NBT;
   // element offsets from the kernel-argument base pointers (kept as offsets so that the loads stay
   // global_load: pointer arrays that are advanced in the loop degrade to flat loads + scratch)
   const float* __restrict__ gA = p.h_prev;
@@ -55,14 +63,15 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_kernel(RnnLargeArgs p) 
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int idx = tid + 256 * i;
-    const int row = min(m0 + (idx >> 3), p.live - 1);
-    oa[i] = (long)row * H + 4 * (idx & 7);
+    const int row = min(m0 + idx / RL_F4, p.live - 1);
+    oa[i] = (long)row * H + 4 * (idx % RL_F4);
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = tid + 256 * i;
-    const int br = idx >> 3;                              // 0 .. G*32-1: gate br / 32, unit br % 32
-    ob[i] = (long)((br >> 5) * H + u0 + (br & 31)) * H + 4 * (idx & 7);
+    const int br = min(idx / RL_F4, G * RL_BU - 1);       // 0 .. G*32-1: gate br / 32, unit br % 32 (GRU: the
+                                                          // surplus threads of the last pass re-load the last row)
+    ob[i] = (long)((br >> 5) * H + u0 + (br & 31)) * H + 4 * (idx % RL_F4);
   }
   int kload = 0;                                          // k of the next chunk to load
   f32x4 sa[NA], sb[NB];
@@ -80,11 +89,12 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_kernel(RnnLargeArgs p) 
   do {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                             \
       const int idx = tid + 256 * i;                                                             \
-      *reinterpret_cast<f32x4*>(&As[buf][(idx >> 3) * RL_LD + 4 * (idx & 7)]) = sa[i];           \
+      *reinterpret_cast<f32x4*>(&As[buf][(idx / RL_F4) * RL_LD + 4 * (idx % RL_F4)]) = sa[i];           \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                             \
       const int idx = tid + 256 * i;                                                             \
-      *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 3) * RL_LD + 4 * (idx & 7)]) = sb[i];           \
+      if (NB_EXACT || idx < NBT)                                                                 \
+        *reinterpret_cast<f32x4*>(&Bs[buf][(idx / RL_F4) * RL_LD + 4 * (idx % RL_F4)]) = sb[i];  \
     }                                                                                            \
   } while (0)
 
