@@ -118,6 +118,110 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(TiledArgs p) {
   gemm_tiled_body<BM, BN, TA, TB>(p, blockIdx.z, gridDim.z);
 }
 
+// C = act(A W^T + bias) with BOTH operands k-contiguous (A[m][k], W[n][k]) and K a multiple of 16: the
+// main loop of rnn_large_step_kernel (LDS rows of 16 + 4 floats, conflict-free b128 fragment reads, lane
+// (l31, lhi) takes k = 8q + 4*lhi + (0..3) of its row on both sides, double-buffered, one barrier per
+// 16-wide chunk, 40 KB of LDS: three blocks per CU) with a plain epilogue.  Block tile 128 x 128: wave w
+// owns rows 32w .. 32w+31 and four 32-column blocks.  Rows / columns past the edge load a clamped row and
+// are not stored.  The x-side projections of the decoder (K = 2E = 400) and W_c (K = Hd) take this path.
+constexpr int NT_BK = 16, NT_LD = NT_BK + 4;
+__device__ __forceinline__ void gemm_nt_body(const TiledArgs& p) {
+  __shared__ __attribute__((aligned(16))) float As[2][128 * NT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][128 * NT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const float* __restrict__ gA = p.A;
+  const float* __restrict__ gB = p.B;
+  long oa[2], ob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;                       // piece: row idx / 4, float4 idx % 4 of the chunk
+    oa[i] = (long)min(m0 + (idx >> 2), p.M - 1) * p.lda + 4 * (idx & 3);
+    ob[i] = (long)min(n0 + (idx >> 2), p.N - 1) * p.ldb + 4 * (idx & 3);
+  }
+  int kload = 0;
+  f32x4 sa[2], sb[2];
+#define NT_STAGE_LOAD()                                                                \
+  do {                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                    \
+      sa[i] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload);                     \
+      sb[i] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload);                     \
+    }                                                                                  \
+    kload += NT_BK;                                                                    \
+  } while (0)
+#define NT_STAGE_STORE(buf)                                                            \
+  do {                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                    \
+      const int idx = tid + 256 * i;                                                   \
+      *reinterpret_cast<f32x4*>(&As[buf][(idx >> 2) * NT_LD + 4 * (idx & 3)]) = sa[i]; \
+      *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 2) * NT_LD + 4 * (idx & 3)]) = sb[i]; \
+    }                                                                                  \
+  } while (0)
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  const int nk = p.K / NT_BK;
+  NT_STAGE_LOAD();
+  NT_STAGE_STORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) NT_STAGE_LOAD();
+    const float* ar = &As[buf][(wave * 32 + l31) * NT_LD + 4 * lhi];
+    const float* br = &Bs[buf][l31 * NT_LD + 4 * lhi];
+#pragma unroll
+    for (int q = 0; q < NT_BK / 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(ar + 8 * q);
+      float4 b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const float4*>(br + g * 32 * NT_LD + 8 * q);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[g].w, acc[g], 0, 0, 0);
+    }
+    if (kt + 1 < nk) NT_STAGE_STORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef NT_STAGE_LOAD
+#undef NT_STAGE_STORE
+  // acc[g][r] = C[m0 + 32*wave + (r&3) + 8*(r>>2) + 4*lhi][n0 + 32*g + l31]
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = n0 + 32 * g + l31;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (m < p.M) {
+        float* c = p.C + (long)m * p.ldc + n;
+        float v = apply_act(acc[g][r] + bv, p.act);
+        if (p.beta) v += *c;
+        *c = v;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(TiledArgs p) { gemm_nt_body(p); }
+static bool gemm_nt_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CVAE_GEMM_NT"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+// plain A, transposed B, K % 16 == 0, 16-byte aligned rows, no CE-gradient epilogue
+static bool gemm_nt_ok(const GemmDesc& d) {
+  return gemm_nt_enabled() && !d.transA && d.transB && d.K >= NT_BK && d.K % NT_BK == 0 && d.act != ACT_CEGRAD &&
+         aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0;
+}
+
 // Batch of products with one B: blockIdx.z = batch; A and C advance by a stride, the row count of
 // every batch comes with the launch (the IW-eval decoder: one slab of live rows per timestep).
 struct TiledBatch { long sA, sC; int m[GEMM_MAX_BATCH]; };
@@ -128,6 +232,14 @@ __global__ __launch_bounds__(256) void gemm_tiled_batched_kernel(TiledArgs p, Ti
   p.A += (long)blockIdx.z * b.sA;
   p.C += (long)blockIdx.z * b.sC;
   gemm_tiled_body<BM, BN, TA, TB>(p, 0, 1);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_batched_kernel(TiledArgs p, TiledBatch b) {
+  p.M = b.m[blockIdx.z];
+  if ((int)blockIdx.y * 128 >= p.M) return;
+  p.A += (long)blockIdx.z * b.sA;
+  p.C += (long)blockIdx.z * b.sC;
+  gemm_nt_body(p);
 }
 
 static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
@@ -154,7 +266,8 @@ static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
   constexpr int BM = 128, BN = 128;
   dim3 grid(cdiv(d.N, BN), cdiv(mmax, BM), d.nbatch);
   ProfScope prof(PK_GEMM_TILED, s, 2.0 * rows * d.N * d.K);
-  if (d.transB) hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, b);
+  if (gemm_nt_ok(d) && d.batchA % 4 == 0) hipLaunchKernelGGL(gemm_nt_batched_kernel, grid, dim3(256), 0, s, a, b);
+  else if (d.transB) hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, b);
   else hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a, b);
   CVAE_LAUNCH_CHECK("gemm_tiled_batched");
   return 0;
@@ -191,6 +304,11 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
   }
   dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), ksplit);
   ProfScope prof(PK_GEMM_TILED, s, 2.0 * d.M * d.N * d.K);
+  if (BM == 128 && BN == 128 && ksplit == 1 && gemm_nt_ok(d)) {
+    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+    CVAE_LAUNCH_CHECK("gemm_nt");
+    return 0;
+  }
   if (!d.transA && d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a);
   else if (!d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a);
   else if (d.transA && !d.transB) hipLaunchKernelGGL((gemm_tiled_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a);

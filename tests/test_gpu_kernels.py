@@ -58,6 +58,10 @@ GEMM_CASES = [
     (2100, 1540, 200, 0, 1, 1, 1, 0),      # ragged M / N, bias + tanh, K tail of 8
     (3000, 1100, 36, 0, 1, 0, 0, 1),       # short K with a 4-wide tail, accumulate
     (1600, 2048, 512, 0, 1, 0, 2, 0),      # relu
+    # K % 16 == 0: the k-contiguous kernel (gemm_nt_kernel); ragged M / N, epilogues, accumulate
+    (2100, 1540, 208, 0, 1, 1, 2, 0),
+    (3000, 1100, 48, 0, 1, 0, 0, 1),
+    (2049, 1537, 16, 0, 1, 1, 3, 0),
 ]
 
 
