@@ -8,8 +8,9 @@
 // launch, operand fetch (W_hh is re-read from L2 every step) and drain, plus ~1.5 us of kernel
 // boundary.  Here every block keeps ITS slice of W_hh resident for the whole sequence and the steps
 // are separated by an in-kernel all-gather of the 32 x H state:
-//   * grid = (H / 4) blocks per sequence, one block per CU (<= 256 blocks in all): block b owns
-//     hidden units 4b .. 4b+3, i.e. 4*G gate columns (forward) or 4 columns of dh (backward);
+//   * forward: grid = (H / 4) blocks per sequence, one block per CU (<= 256 blocks in all): block b owns
+//     hidden units 4b .. 4b+3, i.e. 4*G gate columns; backward: H / 8 blocks per sequence, block b owns
+//     8 units (half the blocks, flags and exchange volume: rnn_bwd_persist_kernel<CELL, HU>);
 //   * forward step:  gates[32 x 4G] = h_{t-1}[32 x H] . W_hh[4G rows]^T with v_mfma_f32_16x16x4_f32,
 //     K split over the block's waves (W fragments live in registers), partial tiles summed through
 //     LDS, then 128 threads run the cell for their (row, unit) and publish h_t;
