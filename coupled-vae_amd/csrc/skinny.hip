@@ -369,7 +369,6 @@ int launch_skinny_multi(const SkinnyArgs* arr, int n, int epi, hipStream_t s) {
   if (nw > maxw) nw = maxw;
   if (nw > nkb) nw = nkb;
   if (nw < 1) nw = 1;
-  const size_t lds = (size_t)nw * mt * ng * 256 * sizeof(float);
   dim3 grid(cdiv(a.N, 16), cdiv(a.M, 16 * mt), n);
   ProfScope prof(PK_SKINNY, s, 2.0 * a.M * a.N * a.K * ng * n);
   // guard-free kernel when the block tiling covers the problem exactly
