@@ -839,16 +839,20 @@ int64_t cvae_projce_workspace(int64_t N, int64_t E, int64_t V) {
   return projce_workspace_floats((int)N, (int)V);
 }
 
-int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                        int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
-                        float* ws, void* stream) {
+int64_t cvae_projce_logits_workspace(int64_t N, int64_t E, int64_t V) {
+  return ce_fast_supported((int)E) ? ce_fast_logits_floats(N, (int)V) : 0;
+}
+
+static int projce_forward_impl(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                               int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                               float* ws, float* logits, void* stream) {
   hipStream_t s = S(stream);
   CVAE_REQUIRE(nseg >= 1 && T >= 0 && R >= 0 && (int64_t)nseg * T * R < (1LL << 31) && V > 0 && V < (1LL << 31),
                "projce_forward: bad shape");
   const long TR = (long)T * R, N = TR * nseg;
   if (N == 0) return 0;
   if (ce_fast_supported(E)) {
-    CVAE_TRY(launch_ce_fast_forward(final, W, b, tgt, pad, N, TR, E, (int)V, loss_row, lse, ws, s));
+    CVAE_TRY(launch_ce_fast_forward(final, W, b, tgt, pad, N, TR, E, (int)V, loss_row, lse, ws, logits, s));
   } else {
     for (int g = 0; g < nseg; ++g)
       CVAE_TRY(launch_projce_forward(final + g * TR * E, W, b, tgt, pad, (int)TR, E, (int)V, loss_row + g * TR,
@@ -859,21 +863,33 @@ int cvae_projce_forward(const float* final, const float* W, const float* b, cons
   return 0;
 }
 
+int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                        int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                        float* ws, void* stream) {
+  return projce_forward_impl(final, W, b, tgt, pad, nseg, T, R, E, V, loss_row, lse, sent, ws, nullptr, stream);
+}
+int cvae_projce_forward_train(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                              int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                              float* ws, float* logits, void* stream) {
+  CVAE_REQUIRE(!logits || ce_fast_supported(E), "projce_forward_train: logits are only saved for E <= 200");
+  return projce_forward_impl(final, W, b, tgt, pad, nseg, T, R, E, V, loss_row, lse, sent, ws, logits, stream);
+}
+
 int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {
   if (ce_fast_supported((int)E)) return ce_fast_bwd_workspace_floats(N, (int)V);
   return projce_bwd_workspace_floats((int)N, (int)V) + N;   // + broadcast of gsent over time
 }
 
-int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
-                         const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
-                         float* dfinal, float* dW, float* db, float* ws, void* stream) {
+static int projce_backward_impl(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                                const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                                float* dfinal, float* dW, float* db, float* ws, float* logits, void* stream) {
   hipStream_t s = S(stream);
   CVAE_REQUIRE(nseg >= 1 && T >= 0 && R >= 0 && (int64_t)nseg * T * R < (1LL << 31) && V > 0 && V < (1LL << 31),
                "projce_backward: bad shape");
   CVAE_REQUIRE(gsent && ws && dW && db, "projce_backward: null operand");
   const long TR = (long)T * R, N = TR * nseg;
   if (ce_fast_supported(E))
-    return launch_ce_fast_backward(final, W, b, tgt, pad, lse, gsent, N, TR, R, E, (int)V, dfinal, dW, db, ws, s);
+    return launch_ce_fast_backward(final, W, b, tgt, pad, lse, gsent, N, TR, R, E, (int)V, dfinal, dW, db, ws, logits, s);
   CVAE_TRY(launch_zero(dW, (long)V * E, s));
   CVAE_TRY(launch_zero(db, (long)V, s));
   for (int g = 0; g < nseg; ++g) {
@@ -883,6 +899,18 @@ int cvae_projce_backward(const float* final, const float* W, const float* b, con
                                     dfinal + g * TR * E, dW, db, ws + TR, s));
   }
   return 0;
+}
+
+int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                         const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                         float* dfinal, float* dW, float* db, float* ws, void* stream) {
+  return projce_backward_impl(final, W, b, tgt, pad, lse, gsent, nseg, T, R, E, V, dfinal, dW, db, ws, nullptr, stream);
+}
+int cvae_projce_backward_saved(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                               const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                               float* dfinal, float* dW, float* db, float* ws, float* logits, void* stream) {
+  CVAE_REQUIRE(logits && ce_fast_supported(E), "projce_backward_saved: needs the logits saved by projce_forward_train");
+  return projce_backward_impl(final, W, b, tgt, pad, lse, gsent, nseg, T, R, E, V, dfinal, dW, db, ws, logits, stream);
 }
 
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream) {

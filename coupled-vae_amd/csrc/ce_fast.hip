@@ -144,7 +144,10 @@ __device__ __forceinline__ void lse_merge2(float& m, float& s, float m2, float s
 }
 
 // NQ: K is covered by NQ groups of 8 (zero padded): E <= 8*NQ <= 200.
-template <int NQ, bool GRAD, bool EXACT>
+// SAVE (forward of a training step): also store the logits of the live rows, S[live index][v], so that the
+// backward pass turns them into the gradient in place (ce_grad_from_logits_kernel) instead of recomputing
+// the product.  The stores ride along with an MFMA-bound kernel.
+template <int NQ, bool GRAD, bool EXACT, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void ce_core_kernel(CeArgs p) {
   __shared__ __attribute__((aligned(16))) float Wt[2][CE_TN * CE_LDW];
   constexpr int F4ROW = 2 * NQ;                 // float4 per W row
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void ce_core_kernel(CeArgs p) {
       }
       prow = p.P + (long)(ci - p.r0) * p.ldp;
     }
+    if (SAVE) prow = p.P + (long)ci * p.ldp;
 
     stage_load(t0);
     stage_store(0);
@@ -289,6 +293,12 @@ __global__ __launch_bounds__(256, 2) void ce_core_kernel(CeArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (jt == (r & 3) + 8 * (r >> 2)) { tlv = xv[r]; found = true; }
+        if (SAVE && rv) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(prow + n0 + 8 * g + 4 * lhi) =
+                make_float4(xv[4 * g], xv[4 * g + 1], xv[4 * g + 2], xv[4 * g + 3]);
+        }
       } else {
         const int jt = tg - n0 - 4 * lhi;
 #pragma unroll
@@ -334,6 +344,33 @@ __global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, fl
   loss[n] = l - p.tl[i];
 }
 
+// P[i][v] = coef * (exp(S[i][v] - lse) - (v == target)) in place on the logits the forward pass saved, for
+// the live rows [0, *nlive): 2 x 4 bytes per logit of HBM traffic instead of the E-long product again.
+__global__ __launch_bounds__(256) void ce_grad_from_logits_kernel(CeArgs p) {
+  const int nlive = *p.nlive;
+  const int V4 = p.V / 4;
+  for (int ci = blockIdx.x; ci < nlive; ci += gridDim.x) {
+    const int n = p.rows[ci];
+    const float lse_r = p.lse[n];
+    const float coef = p.gsent[(n / p.TR) * p.R + n % p.R];
+    const int64_t t = p.tgt[n % p.TR];
+    const int tg = (t >= 0 && t < p.V) ? (int)t : -1;
+    float* row = p.P + (long)ci * p.ldp;
+    float4* row4 = reinterpret_cast<float4*>(row);
+    for (int i = threadIdx.x; i < V4; i += 256) {
+      float4 x = row4[i];
+      const int v = 4 * i;
+      x.x = coef * (__expf(x.x - lse_r) - (v == tg ? 1.f : 0.f));
+      x.y = coef * (__expf(x.y - lse_r) - (v + 1 == tg ? 1.f : 0.f));
+      x.z = coef * (__expf(x.z - lse_r) - (v + 2 == tg ? 1.f : 0.f));
+      x.w = coef * (__expf(x.w - lse_r) - (v + 3 == tg ? 1.f : 0.f));
+      row4[i] = x;
+    }
+    for (int v = 4 * V4 + threadIdx.x; v < p.V; v += 256)
+      row[v] = coef * (__expf(row[v] - lse_r) - (v == tg ? 1.f : 0.f));
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 static int ce_cap(long N, int V) {
@@ -363,14 +400,14 @@ static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* ro
   return 0;
 }
 
-template <bool GRAD>
+template <bool GRAD, bool SAVE = false>
 static int launch_core(const CeArgs& a, hipStream_t s) {
   const dim3 grid(persistent_grid_blocks()), block(256);
   const int nq = (a.E + 7) / 8;
 #define CE_CASE(NQ_)                                                                          \
   do {                                                                                        \
-    if (a.vec && a.E == 8 * NQ_) hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, true>), grid, block, 0, s, a);  \
-    else hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, false>), grid, block, 0, s, a);        \
+    if (a.vec && a.E == 8 * NQ_) hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, true, SAVE>), grid, block, 0, s, a);  \
+    else hipLaunchKernelGGL((ce_core_kernel<NQ_, GRAD, false, SAVE>), grid, block, 0, s, a);        \
   } while (0)
   if (nq <= 2) CE_CASE(2);
   else if (nq <= 4) CE_CASE(4);
@@ -393,8 +430,13 @@ static long live_rows_for_profile(const int* nlive, long N, hipStream_t s) {
 }
 
 // X [nseg*TR, E]; tgt [TR]; loss, lse [nseg*TR]
+static long ce_ldp(int V) { return (long)cdiv(V, CE_TN) * CE_TN; }
+long ce_fast_logits_floats(long N, int V) { return ((N + CE_ROWS - 1) / CE_ROWS * CE_ROWS) * ce_ldp(V); }
+
+// logits: null, or ce_fast_logits_floats(N, V) floats (16-byte aligned) that receive the logits of the live rows
 int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
-                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, hipStream_t s) {
+                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, float* logits,
+                           hipStream_t s) {
   CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && N % TR == 0 && N < (1L << 31), "ce_forward: bad shape");
   if (N == 0) return 0;
   CVAE_REQUIRE(X && W && bias && tgt && loss && lse && ws, "ce_forward: null operand");
@@ -412,14 +454,19 @@ int launch_ce_fast_forward(const float* X, const float* W, const float* bias, co
   {
     const long live = live_rows_for_profile(nlive, N, s);
     ProfScope prof(PK_CE_FWD, s, 2.0 * live * E * V);
-    CVAE_TRY(launch_core<false>(a, s));
+    if (logits) {
+      CVAE_REQUIRE(aligned16(logits), "ce_forward: logits buffer must be 16-byte aligned");
+      a.P = logits; a.ldp = ce_ldp(V);
+      CVAE_TRY((launch_core<false, true>(a, s)));
+    } else {
+      CVAE_TRY(launch_core<false>(a, s));
+    }
   }
   hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, persistent_grid_blocks(), loss, lse);
   CVAE_LAUNCH_CHECK("ce_combine2_kernel");
   return 0;
 }
 
-static long ce_ldp(int V) { return (long)cdiv(V, CE_TN) * CE_TN; }
 static long ce_chunk_rows(long N, int V) {
   static long mb = -1;
   if (mb < 0) {
@@ -441,7 +488,7 @@ long ce_fast_bwd_workspace_floats(long N, int V) {
 // dX [N,E] overwritten; dW [V,E], db [V] overwritten.
 int launch_ce_fast_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
                             const float* lse, const float* gsent, long N, long TR, int R, int E, int V,
-                            float* dX, float* dW, float* db, float* ws, hipStream_t s) {
+                            float* dX, float* dW, float* db, float* ws, float* logits, hipStream_t s) {
   CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && R > 0 && TR % R == 0 && N % TR == 0 && N < (1L << 31),
                "ce_backward: bad shape");
   ZeroBatch zb(s);
@@ -456,8 +503,14 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
   int* nlive = counts + ce_counts_slots(N) - 4;
   float* P = ws + N + ce_counts_slots(N) + 16;
   P = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(P) + 15) & ~(uintptr_t)15);
-  const long ldp = ce_ldp(V), CH = ce_chunk_rows(N, V);
-  float* part = P + CH * ldp;
+  // logits != null: the forward pass saved the logits of ALL live rows there; they become the gradient in
+  // place and the two products run once over all rows (no chunking, nothing recomputed)
+  const long ldp = ce_ldp(V), CH = logits ? (N + CE_ROWS - 1) / CE_ROWS * CE_ROWS : ce_chunk_rows(N, V);
+  float* part = logits ? P : P + CH * ldp;
+  if (logits) {
+    CVAE_REQUIRE(aligned16(logits), "ce_backward: logits buffer must be 16-byte aligned");
+    P = logits;
+  }
   part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(part) + 15) & ~(uintptr_t)15);
   CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, nullptr, nullptr, nullptr, s));
   CeArgs a = {};
@@ -472,7 +525,12 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
     if (lrc > rc) lrc = rc;
     if (lrc < 0) lrc = 0;
     a.r0 = (int)r0; a.rcount = rc;
-    {
+    if (logits) {
+      a.P = P;
+      const int nblk = (int)(rc < 8192 ? rc : 8192);
+      hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, a);
+      CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
+    } else {
       ProfScope prof(PK_CE_FWD, s, 2.0 * lrc * E * V);
       CVAE_TRY(launch_core<true>(a, s));
     }

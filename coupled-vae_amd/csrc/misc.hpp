@@ -87,10 +87,12 @@ int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStre
 bool ce_fast_supported(int E);
 long ce_fast_workspace_floats(long N, int V);
 int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
-                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, hipStream_t s);
+                           long N, long TR, int E, int V, float* loss, float* lse, float* ws, float* logits,
+                           hipStream_t s);
+long ce_fast_logits_floats(long N, int V);
 long ce_fast_bwd_workspace_floats(long N, int V);
 int launch_ce_fast_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
                             const float* lse, const float* gsent, long N, long TR, int R, int E, int V,
-                            float* dX, float* dW, float* db, float* ws, hipStream_t s);
+                            float* dX, float* dW, float* db, float* ws, float* logits, hipStream_t s);
 
 }  // namespace cvae

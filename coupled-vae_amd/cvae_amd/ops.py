@@ -8,6 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .settings import settings
 from ._lib import call, ptr, ptr_array, query, stream
 
 GRU, LSTM = 0, 1
@@ -502,9 +503,21 @@ class ProjCEFn(torch.autograd.Function):
         N = T * R
         loss_row, lse, sent = _f((N,), final), _f((N,), final), _f((R,), final)
         ws = _f((query('cvae_projce_workspace', N, E, V),), final)
-        call('cvae_projce_forward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, 1, T, R, E, V, ptr(loss_row),
-             ptr(lse), ptr(sent), ptr(ws), stream())
+        # training step: the forward pass also saves the logits of the live rows and the backward pass
+        # turns them into the gradient in place instead of recomputing the product (settings.ce_save_logits)
+        logits = None
+        if any(ctx.needs_input_grad) and settings.ce_save_logits:
+            n = query('cvae_projce_logits_workspace', N, E, V)
+            if 0 < n * 4 <= settings.ce_save_logits_max_bytes:
+                logits = _f((n,), final)
+        if logits is not None:
+            call('cvae_projce_forward_train', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, 1, T, R, E, V,
+                 ptr(loss_row), ptr(lse), ptr(sent), ptr(ws), ptr(logits), stream())
+        else:
+            call('cvae_projce_forward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), pad, 1, T, R, E, V, ptr(loss_row),
+                 ptr(lse), ptr(sent), ptr(ws), stream())
         ctx.pad = pad
+        ctx.logits = logits
         ctx.save_for_backward(final, W, b, tgt_tm, lse)
         return sent
 
@@ -516,8 +529,13 @@ class ProjCEFn(torch.autograd.Function):
         gsent = _c(gsent)
         dfinal, dW, db = torch.empty_like(final), torch.empty_like(W), torch.empty_like(b)
         ws = _f((query('cvae_projce_backward_workspace', T * R, E, V),), final)
-        call('cvae_projce_backward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent), 1, T, R, E,
-             V, ptr(dfinal), ptr(dW), ptr(db), ptr(ws), stream())
+        logits, ctx.logits = ctx.logits, None            # consumed (overwritten with the gradient)
+        if logits is not None:
+            call('cvae_projce_backward_saved', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent),
+                 1, T, R, E, V, ptr(dfinal), ptr(dW), ptr(db), ptr(ws), ptr(logits), stream())
+        else:
+            call('cvae_projce_backward', ptr(final), ptr(W), ptr(b), ptr(tgt_tm), ctx.pad, ptr(lse), ptr(gsent), 1, T,
+                 R, E, V, ptr(dfinal), ptr(dW), ptr(db), ptr(ws), stream())
         return dfinal, dW, db, None, None
 
 

@@ -7,6 +7,8 @@ class _Settings(object):
     iw_max_rows = 16384       # rows (samples x sentences) decoded per pass in IW evaluation
     sort_eval = True          # IW eval: sentence-major rows ordered by length, finished rows are skipped (exact)
     pair_encoders = True      # dialogue model: post and response encoders in the same launches (ops.encoder_pair)
+    ce_save_logits = True     # training: keep the live rows' logits from the CE forward for its backward (no recompute)
+    ce_save_logits_max_bytes = 8 << 30   # per call; above it the backward recomputes
     shard_samples = False     # multi-GPU IW eval: shard the K samples of every sentence over ranks (dist_utils)
     truncate_eval = True      # cut T to max(len)+1 in test_lm (exact: pad targets weigh 0)
 

@@ -203,6 +203,18 @@ int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V);
 int cvae_projce_backward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
                          const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
                          float* dfinal, float* dW, float* db, float* ws, void* stream);
+/* Training-step variant that does not recompute the projection in backward (E <= 200):
+ * cvae_projce_forward_train also stores the logits of the live (non-pad) rows into `logits`
+ * (cvae_projce_logits_workspace(N, E, V) floats, 16-byte aligned; 0 = not supported for this E), and
+ * cvae_projce_backward_saved turns them into d loss / d logits IN PLACE (the buffer is consumed) before
+ * the same two products as cvae_projce_backward.  Results equal the plain pair's. */
+int64_t cvae_projce_logits_workspace(int64_t N, int64_t E, int64_t V);
+int cvae_projce_forward_train(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                              int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
+                              float* ws, float* logits, void* stream);
+int cvae_projce_backward_saved(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
+                               const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
+                               float* dfinal, float* dW, float* db, float* ws, float* logits, void* stream);
 /* tgt_tm[t*R + r] = eos[(r % B)*T + t]: time-major targets for R = n*B rows. */
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream);
 /* tgt_tm[t*B*K + r] = eos[(r / K)*T + t]: the same for sentence-major rows r = b*K + k. */

@@ -342,13 +342,21 @@ def test_projce_forward_backward(dev, shape):
     P = {'D.ToVocab.weight': W.double().requires_grad_(True), 'D.ToVocab.bias': b.double().requires_grad_(True)}
     ref = O.seq_xent(P, 'D.', f64, eos)
     (ref * gs.double()).sum().backward()
-    fd, Wd, bd = (t.to(dev).requires_grad_(True) for t in (final, W, b))
-    got = ops.proj_ce(fd, Wd, bd, eos.to(dev), 0)
-    assert rel(got, ref) < 2e-5
-    (got * gs.to(dev)).sum().backward()
-    assert rel(fd.grad, f64.grad) < 1e-4
-    assert rel(Wd.grad, P['D.ToVocab.weight'].grad) < 1e-4
-    assert rel(bd.grad, P['D.ToVocab.bias'].grad) < 1e-4
+    from cvae_amd import settings
+    # both backward variants: logits saved by the forward pass and turned into the gradient in place
+    # (default), and the projection recomputed in backward
+    try:
+        for save in (True, False):
+            settings.ce_save_logits = save
+            fd, Wd, bd = (t.to(dev).requires_grad_(True) for t in (final, W, b))
+            got = ops.proj_ce(fd, Wd, bd, eos.to(dev), 0)
+            assert rel(got, ref) < 2e-5
+            (got * gs.to(dev)).sum().backward()
+            assert rel(fd.grad, f64.grad) < 1e-4
+            assert rel(Wd.grad, P['D.ToVocab.weight'].grad) < 1e-4
+            assert rel(bd.grad, P['D.ToVocab.bias'].grad) < 1e-4
+    finally:
+        settings.ce_save_logits = True
     lg = ops.logits_bt(fd, Wd, bd)
     assert rel(lg, O.decoder_logits(P, 'D.', f64)) < 2e-5
 
