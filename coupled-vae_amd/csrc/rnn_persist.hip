@@ -481,7 +481,10 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     }
     __syncthreads();
     P_STAMP(3);
-    // product: two 16-row fragments x this wave's column fragments, K = NC (KS steps)
+    // product: two 16-row fragments x this wave's column fragments, K = NC (KS steps).  Rows at or past
+    // this step's bound have an all-zero dG: a 16-row fragment wholly past it is neither multiplied nor
+    // written (its part of the tile is not published either).
+    const int rb_cur = row_bound(t);
     {
       float a[2][KS];
 #pragma unroll
@@ -492,17 +495,20 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
       for (int j = 0; j < 2; ++j) {
         const int nf = wave + 16 * j;
         if (nf < nfr) {
-          f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], w[j][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], w[j][s], acc1, 0, 0, 0);
-          }
           // C layout: acc[r] = (row 16f + 4*kq + r, column 16*nf + l15)
+          if (rb_cur > 0) {
+            f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            tile[(4 * kq + r) * LDT + 16 * nf + l15] = acc0[r];
-            tile[(16 + 4 * kq + r) * LDT + 16 * nf + l15] = acc1[r];
+            for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], w[j][s], acc0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(4 * kq + r) * LDT + 16 * nf + l15] = acc0[r];
+          }
+          if (rb_cur > 16) {
+            f32x4v acc1 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], w[j][s], acc1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(16 + 4 * kq + r) * LDT + 16 * nf + l15] = acc1[r];
           }
         }
       }
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     // ex[parity][d][me][r][4*part ..]
     {
       const long wbase = (long)((T - i) & 1) * ex_par + (long)blockIdx.x * PIECE;
-      rb_prev = row_bound(t);
+      rb_prev = rb_cur;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int gq = tid + P_THREADS * j;
