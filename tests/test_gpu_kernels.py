@@ -488,3 +488,33 @@ def test_pack_batch_from_resident_corpus(dev):
             b = c.batch_resident(idx, trunc)
             for x, y in zip(a, b):
                 assert x.dtype == torch.int64 and torch.equal(x, y)
+
+
+def test_decode_entry_point_limits(dev):
+    """Greedy at the row maximum (B = 256), beam at K*B = 256, and the refusals just past them."""
+    from cvae_amd import ops, _lib
+    g = torch.Generator().manual_seed(3)
+    E, Hd, V, T = 8, 16, 40, 5
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)
+    w = [r(3 * Hd, 2 * E), r(3 * Hd, Hd), r(3 * Hd), r(3 * Hd), r(E, Hd), r(E)]
+    emb, Wv, bv = r(V, E), r(V, E), r(V)
+    P = {'D.GRU.weight_ih_l0': w[0], 'D.GRU.weight_hh_l0': w[1], 'D.GRU.bias_ih_l0': w[2], 'D.GRU.bias_hh_l0': w[3],
+         'D.W_c.weight': w[4], 'D.W_c.bias': w[5], 'D.Embedding.weight': emb, 'D.ToVocab.weight': Wv, 'D.ToVocab.bias': bv}
+    P = {k: v.double().cpu() for k, v in P.items()}
+    for B, K in ((256, 1), (32, 8), (128, 2)):
+        init, first = r(B, E), torch.randint(4, V, (B,), generator=g).to(dev)
+        if K == 1:
+            ids = ops.decoder_greedy(ops.GRU, init, first, T, emb, w, Wv, bv)
+            ref = O.decoder_greedy(P, 'D.', 'gru', init.double().cpu(), first.cpu(), T)
+        else:
+            ids = ops.decoder_beam(ops.GRU, init, first, T, K, emb, w, Wv, bv)
+            ref = O.decoder_beam(P, 'D.', 'gru', init.double().cpu(), first.cpu(), T, K)[0]
+        assert int((ids.cpu() != ref).any(1).sum()) == 0, (B, K)
+    init, first = r(257, E), torch.randint(4, V, (257,), generator=g).to(dev)
+    with pytest.raises(_lib.CvaeHipError):
+        ops.decoder_greedy(ops.GRU, init, first, T, emb, w, Wv, bv)
+    init, first = r(33, E), torch.randint(4, V, (33,), generator=g).to(dev)
+    with pytest.raises(_lib.CvaeHipError):
+        ops.decoder_beam(ops.GRU, init, first, T, 8, emb, w, Wv, bv)          # K*B = 264
+    with pytest.raises(_lib.CvaeHipError):
+        ops.decoder_beam(ops.GRU, init[:4], first[:4], T, 9, emb, w, Wv, bv)  # K > 8
