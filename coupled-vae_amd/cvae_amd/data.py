@@ -63,17 +63,29 @@ class Corpus(object):
         off = np.cumsum([0] + [len(s) for s in self.sentences]).astype(np.int64)
         self.dev_flat = torch.from_numpy(flat).to(device)
         self.dev_off = torch.from_numpy(off).to(device)
-        self._pinned = torch.empty((4096,), dtype=torch.int64).pin_memory() if torch.cuda.is_available() else None
+        # pinned staging for the per-batch index vector: a ring of slots, each guarded by the event recorded
+        # after its last host->device copy (the host runs ahead of the stream in a training loop, so a slot
+        # must not be overwritten while its copy is still queued)
+        self._ring = [torch.empty((4096,), dtype=torch.int64).pin_memory() for _ in range(8)]
+        self._ring_ev = [None] * len(self._ring)
+        self._ring_next = 0
         return self
 
     def batch_resident(self, idx, truncate=True):
         """Same tensors as batch(), built from the device-resident CSR arrays (to_device first)."""
         idx = np.asarray(list(idx), dtype=np.int64)
         width = int(self.lengths[idx].max()) if truncate else self.max_len
-        if self._pinned is not None and idx.size <= self._pinned.numel():
-            stage = self._pinned[:idx.size]
+        if idx.size <= self._ring[0].numel():
+            k = self._ring_next
+            self._ring_next = (k + 1) % len(self._ring)
+            if self._ring_ev[k] is not None:
+                self._ring_ev[k].synchronize()          # the copy that last read this slot has completed
+            stage = self._ring[k][:idx.size]
             stage.copy_(torch.from_numpy(idx))
             sel = stage.to(self.dev_flat.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev_flat.device))
+            self._ring_ev[k] = ev
         else:
             sel = torch.from_numpy(idx).to(self.dev_flat.device)
         return ops.pack_batch_indexed(self.dev_flat, self.dev_off, sel, self.max_len, width, PAD, GO, EOS)

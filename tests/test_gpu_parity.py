@@ -403,10 +403,10 @@ def test_batch_larger_than_maximum_is_refused(dev):
         tr.forward_backward(harness.text_batch(c, range(257), dev))
 
 
-def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2):
+def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sort_rows=False):
     from cvae_amd import modules, data, harness
     hp = harness.HParams(model=model, cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'],
-                         lambda_couple=2.0 if model.startswith('cvae') else 0.1)
+                         lambda_couple=2.0 if model.startswith('cvae') else 0.1, euclidean_dist=euclid)
     tr = harness.Trainer(hp, dev, seed=3)
     sd = tr.model.state_dict(keep_vars=True)
     P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in sd.items()})
@@ -417,10 +417,10 @@ def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2):
     if hp.is_dialog():
         batch = harness.dialog_batch(c1, c2, range(B), dev)
     else:
-        batch = harness.text_batch(c1, range(B), dev)
+        batch = harness.text_batch(c1, range(B), dev, sort_rows=sort_rows)
     cb = {k: v.cpu() for k, v in batch.items()}
     # a1 cross-check against the oracle's layout
-    if not hp.is_dialog():
+    if not hp.is_dialog() and not sort_rows:
         ob = O.make_batch([x.tolist() for x in sents[:B]], 200, truncate=True)
         for k, v in zip(('bare', 'go', 'eos', 'len'), ob):
             assert np.array_equal(cb[k].numpy(), v)
@@ -440,7 +440,7 @@ def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2):
         noise['enc_drop'] = drop(cb['bare'].shape[1], B, E)
     replay = {k: (v.unsqueeze(0) if k == 'eps' else v) for k, v in noise.items()}
     cfg = dict(latent_dim=Z, lambda_kl=0.37, lambda_couple=hp.lambda_couple, lambda_seq_couple=1.0,
-               euclidean_dist=False)
+               euclidean_dist=euclid)
     tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1     # lambda_KL = 0.37 at the next iter
     modules.set_noise_source(modules.ReplayNoise(replay))
     try:
