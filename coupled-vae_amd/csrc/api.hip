@@ -142,6 +142,7 @@ int cvae_init(int device) {
                "cvae_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                prop.gcnArchName);
   CVAE_TRY(check_hip(hipSetDevice(device), "hipSetDevice"));
+  CVAE_TRY(mi_static_init(device));        // device address of this GPU's copy of the static scratch array
   return 0;
 }
 
@@ -989,6 +990,11 @@ int cvae_mi(const float* z, const float* mu, const float* sigma, int K, int B, i
                void* stream) {
   CVAE_REQUIRE(z && mu && sigma && ws && mi, "mi: null operand");
   return launch_mi(z, mu, sigma, K, B, Z, ws, ws + (long)K * B, mi, S(stream));
+}
+int64_t cvae_mi_static_max_rows(void) { return mi_static_max_rows(); }
+int cvae_mi_static(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* mi, void* stream) {
+  CVAE_REQUIRE(z && mu && sigma && mi, "mi_static: null operand");
+  return launch_mi_static(z, mu, sigma, K, B, Z, mi, S(stream));
 }
 int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
                    int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,

@@ -1143,6 +1143,44 @@ int launch_mi(const float* z, const float* mu, const float* sigma, int K, int B,
   return 0;
 }
 
+// ---- the same estimator for callers that cannot allocate (HIP graph capture, serving loops): the two
+// [K, B] intermediates live in a file-scope device array instead of a caller workspace.  The array's name
+// is only a host-side handle: its device address is looked up once per device (mi_static_init, called by
+// cvae_init with that device current) and that pointer is what the kernels receive.
+constexpr long MI_STATIC_MAX_KB = 131072;                 // K*B limit: 2 x 131072 floats = 1 MiB per GPU
+constexpr int MI_STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[2 * MI_STATIC_MAX_KB];
+static float* g_mi_scratch[MI_STATIC_MAX_DEVICES] = {};   // per device: address of that device's copy
+
+int mi_static_init(int device) {
+  CVAE_REQUIRE(device >= 0 && device < MI_STATIC_MAX_DEVICES, "mi_static_init: device %d out of range", device);
+  if (g_mi_scratch[device]) return 0;
+  float* ptr = nullptr;
+  CVAE_TRY(check_hip(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)),
+                     "mi_static_init: hipGetSymbolAddress(scratch)"));
+  CVAE_REQUIRE(ptr != nullptr, "mi_static_init: null device address for the static scratch array");
+  g_mi_scratch[device] = ptr;
+  return 0;
+}
+
+long mi_static_max_rows() { return MI_STATIC_MAX_KB; }
+
+int launch_mi_static(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* mi,
+                     hipStream_t s) {
+  CVAE_REQUIRE(K > 0 && B > 1 && Z > 0, "mi_static: bad shape K=%d B=%d Z=%d", K, B, Z);
+  CVAE_REQUIRE((long)K * B <= MI_STATIC_MAX_KB,
+               "mi_static: K*B = %ld exceeds the static scratch limit of %ld (use cvae_mi with a workspace)",
+               (long)K * B, MI_STATIC_MAX_KB);
+  int device = -1;
+  CVAE_TRY(check_hip(hipGetDevice(&device), "mi_static: hipGetDevice"));
+  CVAE_REQUIRE(device >= 0 && device < MI_STATIC_MAX_DEVICES && g_mi_scratch[device] != nullptr,
+               "mi_static: cvae_init(%d) has not been called for the current device", device);
+  float* ptr = g_mi_scratch[device];
+  // every element of [0, K*B) of both halves is written by mi_pair_kernel before mi_mean_kernel reads it:
+  // nothing has to start at zero, whatever an earlier (larger) call left behind
+  return launch_mi(z, mu, sigma, K, B, Z, ptr, ptr + (long)K * B, mi, s);
+}
+
 // ------------------------------------------------------------------ clip + Adam (a12)
 // sumsq[0] = sum over all grads^2, sumsq[1] = sum over the alias segment
 __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,

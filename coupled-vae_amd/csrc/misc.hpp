@@ -69,6 +69,11 @@ int launch_iw_reduce(const float* z, const float* xent, const float* mu, const f
                      hipStream_t s);
 int launch_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* lqzx, float* lqz,
               float* mi, hipStream_t s);
+// static-scratch variant (no allocation, no workspace argument): see misc.hip
+int mi_static_init(int device);
+long mi_static_max_rows();
+int launch_mi_static(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* mi,
+                     hipStream_t s);
 int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
                      float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
                      float* sumsq, float* norm_out, hipStream_t s);

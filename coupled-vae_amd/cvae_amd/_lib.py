@@ -72,6 +72,8 @@ SIGNATURES = {
     'cvae_couple_backward': [P, P, P, P, I, I, I, I, P, P],
     'cvae_iw_reduce': [P, P, P, P, P, P, I, I, I, P, P, P, P],
     'cvae_mi': [P, P, P, I, I, I, P, P, P],
+    'cvae_mi_static': [P, P, P, I, I, I, P, P],
+    'cvae_mi_static_max_rows': [],
     'cvae_clip_adam': [P, P, P, P, L, L, L, I, F, F, F, F, F, L, L, P, P, P],
     'cvae_profile_enable': [I],
     'cvae_profile_read': [I, P, P, P],
@@ -80,7 +82,7 @@ SIGNATURES = {
 }
 _RESTYPE_LONG = {'cvae_encoder_backward_scratch', 'cvae_decoder_backward_scratch', 'cvae_projce_workspace',
                  'cvae_decoder_greedy_scratch', 'cvae_projce_logits_workspace', 'cvae_decoder_beam_scratch',
-                 'cvae_projce_backward_workspace'}
+                 'cvae_projce_backward_workspace', 'cvae_mi_static_max_rows'}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync

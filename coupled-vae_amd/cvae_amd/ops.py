@@ -728,6 +728,17 @@ def mi(z, mu, sigma):
     return out
 
 
+def mi_static(z, mu, sigma, out=None):
+    """ops.mi without a workspace allocation (cvae_mi_static: the library's static scratch array, K*B <= 131072).
+    With `out` given the call allocates nothing at all."""
+    z, mu, sigma = _c(z), _c(mu), _c(sigma)
+    K, B, Z = z.shape
+    if out is None:
+        out = _f((B,), z)
+    call('cvae_mi_static', ptr(z), ptr(mu), ptr(sigma), K, B, Z, ptr(out), stream())
+    return out
+
+
 # --------------------------------------------------------------------------- optimizer
 def clip_adam(params, grads, m, v, alias_off, alias_n, alias_mult, max_norm, lr, betas, eps, step_other, step_alias,
               sumsq, norm_out):

@@ -274,6 +274,16 @@ int cvae_iw_reduce(const float* z, const float* xent, const float* mu, const flo
 int cvae_mi(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* ws, float* mi,
             void* stream);
 
+/* ---- cvae_mi for callers that cannot allocate.  No counterpart in the reference: it exists for callers that
+ * cannot call hipMalloc or bring a workspace -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  Same kernels and results as cvae_mi; the two [K,B] intermediates live in a
+ * file-scope device array of the library (1 MiB per GPU, held until the process ends) whose per-device
+ * address cvae_init(device) looks up once.  K*B <= cvae_mi_static_max_rows() (131072), else an error;
+ * cvae_init must have been called for the current device.  Calls no hipMalloc / hipFree.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+int64_t cvae_mi_static_max_rows(void);
+int cvae_mi_static(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* mi, void* stream);
+
 /* ---- a12: clip_grad_norm_ + Adam over a flat parameter arena
  * (Experiment.py:509-522,596-599), with the reference's duplicate-listing behaviour: the
  * segment [alias_off, alias_off+alias_n) (the shared embedding) is listed `alias_mult`
