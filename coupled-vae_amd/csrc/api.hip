@@ -5,6 +5,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "common.hpp"
@@ -60,6 +63,49 @@ ProfScope::~ProfScope() {
   if (slot >= 0) (void)hipEventRecord(g_prof[slot].end, s);
 }
 
+// ---------------------------------------------------------------- library-owned scratch
+struct LibBuf { void* p; size_t bytes; };
+static std::mutex g_scratch_mu;
+static std::map<std::tuple<int, int, hipStream_t>, LibBuf> g_scratch;
+
+int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero, bool* fresh) {
+  CVAE_REQUIRE(kind >= 0 && kind < LS_KINDS && out, "lib_scratch: bad argument");
+  int dev = 0;
+  CVAE_TRY(check_hip(hipGetDevice(&dev), "lib_scratch: hipGetDevice"));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  LibBuf& b = g_scratch[std::make_tuple(kind, dev, s)];
+  if (fresh) *fresh = false;
+  if (bytes > b.bytes) {
+    if (b.p) CVAE_TRY(check_hip(hipFree(b.p), "lib_scratch: hipFree"));          // implicit device sync (warm-up only)
+    b.p = nullptr; b.bytes = 0;
+    CVAE_TRY(check_hip(hipMalloc(&b.p, bytes), "lib_scratch: hipMalloc"));
+    b.bytes = bytes;
+    if (zero) CVAE_TRY(check_hip(hipMemset(b.p, 0, bytes), "lib_scratch: hipMemset"));
+    if (fresh) *fresh = true;
+  }
+  *out = b.p;
+  return 0;
+}
+
+static int* g_status_host = nullptr;     // host address of the mapped word
+static int* g_status_dev = nullptr;      // the same word as the device sees it
+int persist_status_word(int** dev_ptr) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_status_host) {
+    void* h = nullptr;
+    CVAE_TRY(check_hip(hipHostMalloc(&h, 64, hipHostMallocMapped), "persist status: hipHostMalloc"));
+    memset(h, 0, 64);
+    void* d = nullptr;
+    CVAE_TRY(check_hip(hipHostGetDevicePointer(&d, h, 0), "persist status: hipHostGetDevicePointer"));
+    g_status_host = static_cast<int*>(h);
+    g_status_dev = static_cast<int*>(d);
+  }
+  if (dev_ptr) *dev_ptr = g_status_dev;
+  return 0;
+}
+// host-side views for rnn_persist.hip
+int* persist_status_host() { return g_status_host; }
+
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int gates_of(int cell) { return cell == CELL_GRU ? 3 : 4; }
 
@@ -81,17 +127,11 @@ static bool live_rows_enabled() {
   if (on < 0) { const char* e = getenv("CVAE_LIVE_ROWS"); on = (e && e[0] == '0') ? 0 : 1; }
   return on != 0;
 }
-// library-owned index scratch (grown on demand; launches that use it must be on one stream)
-static int* g_rows = nullptr;
-static long g_rows_ints = 0;
-static int lib_rows(long ints, int** out) {
-  if (ints > g_rows_ints) {
-    if (g_rows) CVAE_TRY(check_hip(hipFree(g_rows), "live-row scratch free"));          // implicit device sync
-    g_rows = nullptr; g_rows_ints = 0;
-    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_rows), (size_t)ints * sizeof(int)), "live-row scratch"));
-    g_rows_ints = ints;
-  }
-  *out = g_rows;
+// library-owned index scratch, per stream (lib_scratch)
+static int lib_rows(long ints, int** out, hipStream_t s) {
+  void* p = nullptr;
+  CVAE_TRY(lib_scratch(LS_ROWS, s, (size_t)ints * sizeof(int), &p));
+  *out = static_cast<int*>(p);
   return 0;
 }
 
@@ -330,7 +370,7 @@ static int encoder_backward_impl(int ne, int cell, int B, int L, int E, int H, c
   const bool use_live = live_rows_enabled() && (long)L * B >= 1024;
   const long per_list = 16 + (long)L * B;
   int* buf = nullptr;
-  if (use_live) CVAE_TRY(lib_rows(ne * per_list, &buf));
+  if (use_live) CVAE_TRY(lib_rows(ne * per_list, &buf, s));
   for (int e = 0; e < ne; ++e) {
     const EncBwd& q = ee[e];
     float* dX = q.scratch + 2 * per_dir;
@@ -710,7 +750,7 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   const long per_dec = (4L * B + 16 + (long)T * B + (long)T1 * B + 3) / 4 * 4;     // ints per decoder
   int* rows_buf = nullptr;
   if (use_live) {
-    CVAE_TRY(lib_rows((long)nd * per_dec, &rows_buf));   // shared with the encoder's list: calls are stream-ordered
+    CVAE_TRY(lib_rows((long)nd * per_dec, &rows_buf, s));   // shared with the encoder's list: calls are stream-ordered
   }
   for (int d = 0; d < nd; ++d) {
     const DecBwd& q = dd[d];
@@ -1004,6 +1044,12 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
                           step_other, step_alias, sumsq, norm_out, S(stream));
 }
 int cvae_persist_status(void) { return persist_status_and_clear(); }
+int cvae_persist_status_peek(void) { return persist_status_peek(); }
+int cvae_persist_status_set(int value) {
+  CVAE_TRY(persist_status_word(nullptr));
+  __atomic_store_n(persist_status_host(), value ? 1 : 0, __ATOMIC_RELEASE);
+  return 0;
+}
 
 int cvae_sum_time(const float* x, int T, int R, float* out, void* stream) {
   return launch_sum_time(x, T, R, out, S(stream));

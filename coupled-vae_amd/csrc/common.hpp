@@ -34,7 +34,7 @@ int check_hip(hipError_t e, const char* what);
 // ---- opt-in per-kernel timing (bench.py's roofline leg): HIP events recorded on the launch
 // stream around the kernels named below.  Off by default: no events, no overhead.
 enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_GEMM_WIDE = 5,
-                  PK_RNN_PERSIST = 6, PK_RNN_PERSIST_BWD = 7, PK_COUNT = 8 };
+                  PK_RNN_PERSIST = 6, PK_RNN_PERSIST_BWD = 7, PK_RNN_LARGE = 8, PK_GEMM_NT = 9, PK_COUNT = 10 };
 struct ProfScope {
   int slot;
   hipStream_t s;
@@ -43,6 +43,23 @@ struct ProfScope {
 };
 
 bool prof_enabled();   // true while cvae_profile_enable(1) is in effect
+
+// ---- library-owned device scratch (api.hip): one buffer per (kind, device, stream), so launches on different
+// streams (or host threads driving different streams) never share flag words, exchange slabs or index lists.
+// Allocated at first use and regrown only when a larger shape arrives (warm-up; hipFree of the old buffer
+// synchronises the device); steady-state calls allocate nothing.  Guarded by a mutex.
+enum LibScratchKind { LS_PERSIST_SYNC = 0, LS_PERSIST_EXCH = 1, LS_WIDE_PART = 2, LS_ROWS = 3, LS_KINDS = 4 };
+// zero != 0: a new buffer is zero-filled (synchronously) before it is handed out.  fresh (optional): set when
+// this call (re)allocated.
+int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero = 0, bool* fresh = nullptr);
+// The recurrent kernels' timeout word: ONE int in host-mapped pinned memory (device pointer returned), written
+// by a kernel whose bounded spin ran out; readable on the host without synchronising (cvae_persist_status_peek).
+int persist_status_word(int** dev_ptr);
+// rnn_persist.hip: size of a stream's sync buffer (LS_PERSIST_SYNC) and the spare word in it that holds the
+// device-side copy of the timeout word taken at each optimizer step
+size_t persist_sync_bytes();
+int* persist_status_copy_word(void* sync_buffer);
+int persist_status_peek();
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -265,8 +265,9 @@ static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
   if (mmax == 0) return 0;
   constexpr int BM = 128, BN = 128;
   dim3 grid(cdiv(d.N, BN), cdiv(mmax, BM), d.nbatch);
-  ProfScope prof(PK_GEMM_TILED, s, 2.0 * rows * d.N * d.K);
-  if (gemm_nt_ok(d) && d.batchA % 4 == 0) hipLaunchKernelGGL(gemm_nt_batched_kernel, grid, dim3(256), 0, s, a, b);
+  const bool nt = gemm_nt_ok(d) && d.batchA % 4 == 0;
+  ProfScope prof(nt ? PK_GEMM_NT : PK_GEMM_TILED, s, 2.0 * rows * d.N * d.K);
+  if (nt) hipLaunchKernelGGL(gemm_nt_batched_kernel, grid, dim3(256), 0, s, a, b);
   else if (d.transB) hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, b);
   else hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a, b);
   CVAE_LAUNCH_CHECK("gemm_tiled_batched");
@@ -303,8 +304,9 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
     }
   }
   dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), ksplit);
-  ProfScope prof(PK_GEMM_TILED, s, 2.0 * d.M * d.N * d.K);
-  if (BM == 128 && BN == 128 && ksplit == 1 && gemm_nt_ok(d)) {
+  const bool nt = BM == 128 && BN == 128 && ksplit == 1 && gemm_nt_ok(d);
+  ProfScope prof(nt ? PK_GEMM_NT : PK_GEMM_TILED, s, 2.0 * d.M * d.N * d.K);
+  if (nt) {
     hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
     CVAE_LAUNCH_CHECK("gemm_nt");
     return 0;

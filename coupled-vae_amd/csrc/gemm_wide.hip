@@ -362,18 +362,11 @@ long gemm_wide_part_floats(int N, bool extra) {
   return (long)wide_grid_blocks() * G2_BM * ld;
 }
 
-// Library-owned scratch for callers that bring none (one buffer per process, grown on demand;
-// launches that share it must be on one stream).
-static float* g_part = nullptr;
-static long g_part_floats = 0;
-static int lib_part(long floats, float** out) {
-  if (floats > g_part_floats) {
-    if (g_part) CVAE_TRY(check_hip(hipFree(g_part), "gemm_wide scratch free"));   // implicit device sync
-    g_part = nullptr; g_part_floats = 0;
-    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_part), (size_t)floats * sizeof(float)), "gemm_wide scratch"));
-    g_part_floats = floats;
-  }
-  *out = g_part;
+// Library-owned scratch for callers that bring none: one buffer per stream (lib_scratch).
+static int lib_part(long floats, float** out, hipStream_t s) {
+  void* p = nullptr;
+  CVAE_TRY(lib_scratch(LS_WIDE_PART, s, (size_t)floats * sizeof(float), &p));
+  *out = static_cast<float*>(p);
   return 0;
 }
 
@@ -412,7 +405,7 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
     if (!mc) { const char* e = getenv("CVAE_WIDE_MIN_CHUNKS"); mc = e ? atoi(e) : 4; if (mc < 1 || mc > 256) mc = 4; }
     a.min_chunks = mc;
   }
-  if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part));
+  if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part, s));
   const int nblk = wide_grid_blocks();
   const dim3 grid(nblk), block(256);
   {

@@ -1184,8 +1184,13 @@ int launch_mi_static(const float* z, const float* mu, const float* sigma, int K,
 // ------------------------------------------------------------------ clip + Adam (a12)
 // sumsq[0] = sum over all grads^2, sumsq[1] = sum over the alias segment
 __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const int* __restrict__ status_in,
+                                                     int* __restrict__ status_copy) {
   __shared__ float red[2][16];
+  // one read of the recurrent kernels' timeout word (host-mapped) per optimizer step: clip_adam_kernel
+  // reads the device copy and leaves the parameters alone when a kernel of this step timed out
+  if (blockIdx.x == 0 && threadIdx.x == 0 && status_copy)
+    *status_copy = status_in ? __hip_atomic_load(status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
   float all = 0.f, al = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = g[i];
@@ -1212,7 +1217,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1
                                                         AdamSteps alias_steps, const float* __restrict__ sumsq,
                                                         float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
-                                                        float* __restrict__ norm_out) {
+                                                        float* __restrict__ norm_out,
+                                                        const int* __restrict__ status_copy) {
+  if (status_copy && *status_copy) return;            // invalid gradients (a recurrent kernel timed out): no step
   // total norm as clip_grad_norm_ sees it: the aliased segment is listed `mult` times
   const float total = sqrtf(sumsq[0] + (float)(mult - 1) * sumsq[1]);
   float coef = max_norm / (total + 1e-6f);
@@ -1240,6 +1247,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1
 int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
                      float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
                      float* sumsq, float* norm_out, hipStream_t s) {
+  // timeout word of the whole-sequence recurrent kernels and a device-side copy of it (a spare word of this
+  // stream's sync buffer)
+  int* status_in = nullptr;
+  CVAE_TRY(persist_status_word(&status_in));
+  void* syncbuf = nullptr;
+  CVAE_TRY(lib_scratch(LS_PERSIST_SYNC, s, persist_sync_bytes(), &syncbuf, 1));
+  int* status_copy = persist_status_copy_word(syncbuf);
   CVAE_REQUIRE(n >= 0 && alias_off >= 0 && alias_n >= 0 && alias_off + alias_n <= n && mult >= 1 && mult <= 8,
                "clip_adam: bad segment (alias_mult must be 1..8)");
   if (n == 0) return 0;
@@ -1251,7 +1265,8 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
   int sgrid = cdiv(n, 1024 * 8);
   if (sgrid > 256) sgrid = 256;
   if (sgrid < 1) sgrid = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, sumsq,
+                     status_in, status_copy);
   CVAE_LAUNCH_CHECK("sumsq_kernel");
   AdamSteps so = {}, sa = {};
   so.step_size[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_other + 1))));
@@ -1261,7 +1276,7 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
     sa.bc2_sqrt[r] = (float)sqrt(1.0 - pow((double)b2, (double)(step_alias + 1 + r)));
   }
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, mult,
-                     max_norm, b1, b2, eps, so, sa, sumsq, p, g, m, v, norm_out);
+                     max_norm, b1, b2, eps, so, sa, sumsq, p, g, m, v, norm_out, status_copy);
   CVAE_LAUNCH_CHECK("clip_adam_kernel");
   return 0;
 }

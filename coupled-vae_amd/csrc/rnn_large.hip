@@ -216,7 +216,7 @@ int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "rnn_large LDS attribute"));
     attr_set = true;
   }
-  ProfScope prof(PK_GEMM_TILED, s, 2.0 * live * G * H * (double)H);
+  ProfScope prof(PK_RNN_LARGE, s, 2.0 * live * G * H * (double)H);
   if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_large_step_kernel<CELL_GRU>, grid, block, lds, s, a);
   else hipLaunchKernelGGL(rnn_large_step_kernel<CELL_LSTM>, grid, block, lds, s, a);
   CVAE_LAUNCH_CHECK("rnn_large_step_kernel");

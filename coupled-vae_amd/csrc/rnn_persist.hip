@@ -14,20 +14,21 @@
 //   * forward step:  gates[32 x 4G] = h_{t-1}[32 x H] . W_hh[4G rows]^T with v_mfma_f32_16x16x4_f32,
 //     K split over the block's waves (W fragments live in registers), partial tiles summed through
 //     LDS, then 128 threads run the cell for their (row, unit) and publish h_t;
-//   * backward step: dh_{t-1}[32 x 4] = dG_t[32 x G*H] . W_hh[:, 4 units] with
-//     v_mfma_f32_4x4x1_16b_f32 (16 blocks = 8 row groups x 2 K halves: no padding of the 4-column
-//     tile), W slice in LDS, then the cell backward of step t-1 for the block's units, which
-//     publishes dG_{t-1};
+//   * backward step: the block owns the gate rows of its units, i.e. a K-slice of dh_{t-1} = dG_t . W_hh:
+//     part[32 x H] = dG_t[:, rows of U] . W_hh[rows of U, :] (v_mfma_f32_16x16x4_f32, W slice in registers),
+//     reduce-scattered through a double-buffered destination-major exchange; then the cell backward of
+//     step t-1 for the block's units (details above rnn_bwd_persist_kernel);
 //   * hand-off between blocks (MI355X_MICROARCH.md, inter-workgroup visibility, first table row):
 //     payload stored write-through (`sc1` buffer stores), every storing wave drains (vmcnt(0)),
-//     workgroup barrier, ONE lane adds to the sequence's agent-scope counter; consumers poll that
-//     counter with `sc1` loads (one lane, bounded), barrier, then read the payload with `sc1`
-//     buffer loads.  (Tried and dropped: data-tagged {value, epoch} granules polled directly by the
-//     consumer waves.  16-byte sc1 buffer loads re-reading a line that had been polled before the
-//     store landed kept returning the old copy; 8-byte agent-scope loads were correct but 2x slower
-//     than flag + 16-byte payload loads, and 2000 polling waves slowed the producers' stores.)
-//     Every spin is bounded: on a timeout the block raises the status word and the
-//     whole grid drains (cvae_persist_status reports it).
+//     workgroup barrier, ONE lane stores the block's epoch flag (sc1); consumers poll the per-block flags
+//     with `sc1` loads (one wave, bounded), barrier, then read the payload with `sc1` buffer loads.
+//     (Tried and dropped: one atomic counter per sequence -- 128 arrivals serialise at ~12 ns each; and
+//     data-tagged {value, epoch} granules polled directly by the consumer waves: 16-byte sc1 buffer loads
+//     re-reading a line that had been polled before the store landed kept returning the old copy; 8-byte
+//     agent-scope loads were correct but 2x slower than flag + 16-byte payload loads.)
+//     Every spin is bounded: on a timeout the block raises the status word (host-mapped pinned memory:
+//     cvae_persist_status / _peek read it, cvae_clip_adam refuses to apply a step while it is set) and the
+//     whole grid drains.
 #include "common.hpp"
 #include "misc.hpp"
 #include "cell_math.hpp"
@@ -100,7 +101,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int nb, unsign
       if (++spins > P_SPIN_LIMIT) { bad = 1; break; }
     }
     if (threadIdx.x == 0) {
-      if (bad) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (bad) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word
       *s_abort = bad;
     }
   }
@@ -548,25 +549,27 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
 }
 
 // ------------------------------------------------------------------------------------ host side
-// library-owned sync words: [SKINNY_MAX_BATCH][P_MAXB] epoch flags | 16 status words | 16 stamp accumulators
+// library-owned sync words, one set per stream (lib_scratch): [SKINNY_MAX_BATCH][P_MAXB] epoch flags |
+// 16 spare words | 16 stamp accumulators | int64 [SKINNY_MAX_BATCH][32] zero_after scratch
 constexpr int P_FLAG_WORDS = SKINNY_MAX_BATCH * P_MAXB;
 constexpr size_t P_ZA_OFFSET = (size_t)(P_FLAG_WORDS + 16) * 4 + 16 * 8;      // int64 [SKINNY_MAX_BATCH][32] after the stamps
-static unsigned* g_sync = nullptr;
 static int g_stamps_on = -1;
-static int persist_sync(unsigned** out) {
-  if (!g_sync) {
-    const size_t bytes = P_ZA_OFFSET + (size_t)SKINNY_MAX_BATCH * 32 * 8;
-    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_sync), bytes), "persist sync words"));
-    CVAE_TRY(check_hip(hipMemset(g_sync, 0, bytes), "persist sync memset"));
+static unsigned long long* g_stamps_last = nullptr;      // stamp words of the stream that launched last
+int* persist_status_host();                              // api.hip
+size_t persist_sync_bytes() { return P_ZA_OFFSET + (size_t)SKINNY_MAX_BATCH * 32 * 8; }
+int* persist_status_copy_word(void* sync_buffer) { return reinterpret_cast<int*>(static_cast<unsigned*>(sync_buffer) + P_FLAG_WORDS); }
+static int persist_sync(hipStream_t s, unsigned** out, int** status) {
+  void* p = nullptr;
+  CVAE_TRY(lib_scratch(LS_PERSIST_SYNC, s, persist_sync_bytes(), &p, 1));
+  if (g_stamps_on < 0) {
     const char* e = getenv("CVAE_PERSIST_STAMPS");
     g_stamps_on = (e && e[0] == '1') ? 1 : 0;
   }
-  *out = g_sync;
-  return 0;
+  *out = static_cast<unsigned*>(p);
+  g_stamps_last = g_stamps_on == 1 ? reinterpret_cast<unsigned long long*>(*out + P_FLAG_WORDS + 16) : nullptr;
+  return persist_status_word(status);
 }
-static unsigned long long* persist_stamps() {
-  return g_stamps_on == 1 ? reinterpret_cast<unsigned long long*>(g_sync + P_FLAG_WORDS + 16) : nullptr;
-}
+static unsigned long long* persist_stamps() { return g_stamps_last; }
 
 static int persist_enabled() {
   static int on = -1;
@@ -591,7 +594,8 @@ bool rnn_persist_supported(int cell, int T, int R, int H, int ns) {
 
 int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb) {
   unsigned* sync = nullptr;
-  CVAE_TRY(persist_sync(&sync));
+  int* status = nullptr;
+  CVAE_TRY(persist_sync(s, &sync, &status));
   if (zb) {
     zb->add(reinterpret_cast<float*>(sync), P_FLAG_WORDS);
     CVAE_TRY(zb->flush());
@@ -609,7 +613,7 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch
     if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
   CVAE_REQUIRE(p.nw >= 1 && p.nw <= 16 && p.H % p.nw == 0 && (p.H / p.nw) % 16 == 0 && p.H / p.nw <= 64,
                "rnn_forward_persist: H=%d does not split over the block's waves", p.H);
-  p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
+  p.flags = sync; p.status = status; p.stamps = persist_stamps();
   for (int k = 0; k < ns; ++k) {
     const RnnFwd& r = a[k];
     CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.hs) & 15) == 0 && (!r.cs || (reinterpret_cast<uintptr_t>(r.cs) & 15) == 0) &&
@@ -634,33 +638,28 @@ bool rnn_persist_bwd_supported(int cell, int T, int R, int H, int ns) {
   return on && rnn_persist_supported(cell, T, R, H, ns);
 }
 
-static float* g_exch = nullptr;
-static long g_exch_floats = 0;
-static int persist_exch(long floats, float** out) {
-  if (floats > g_exch_floats) {
-    if (g_exch) CVAE_TRY(check_hip(hipFree(g_exch), "persist exchange free"));     // implicit device sync
-    g_exch = nullptr; g_exch_floats = 0;
-    CVAE_TRY(check_hip(hipMalloc(reinterpret_cast<void**>(&g_exch), (size_t)floats * sizeof(float)), "persist exchange"));
-    g_exch_floats = floats;
-  }
-  *out = g_exch;
+static int persist_exch(hipStream_t s, long floats, float** out) {
+  void* p = nullptr;
+  CVAE_TRY(lib_scratch(LS_PERSIST_EXCH, s, (size_t)floats * sizeof(float), &p));
+  *out = static_cast<float*>(p);
   return 0;
 }
 
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   unsigned* sync = nullptr;
-  CVAE_TRY(persist_sync(&sync));
+  int* status = nullptr;
+  CVAE_TRY(persist_sync(s, &sync, &status));
   CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
   PBwdArgs p = {};
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
-  p.flags = sync; p.status = reinterpret_cast<int*>(sync + P_FLAG_WORDS); p.stamps = persist_stamps();
+  p.flags = sync; p.status = status; p.stamps = persist_stamps();
   const int G = a[0].cell == CELL_GRU ? 3 : 4;
   static int hu_env = 0;                       // CVAE_PERSIST_BWD_HU=4: the 4-unit blocks (more, thinner blocks)
   if (!hu_env) { const char* e = getenv("CVAE_PERSIST_BWD_HU"); hu_env = (e && atoi(e) == 4) ? 4 : 8; }
   const int hu = (hu_env == 8 && p.H % 8 == 0) ? 8 : 4;
   const int nb = p.H / hu;
   CVAE_REQUIRE(p.H % 16 == 0 && p.H / 16 <= 32 && nb <= P_MAXB, "rnn_backward_persist: H=%d", p.H);
-  CVAE_TRY(persist_exch((long)ns * 2 * nb * nb * 32 * hu, &p.exch));
+  CVAE_TRY(persist_exch(s, (long)SKINNY_MAX_BATCH * 2 * nb * nb * 32 * hu, &p.exch));
   for (int k = 0; k < ns; ++k) {
     const RnnBwd& r = a[k];
     float* dgh = r.dgh ? r.dgh : r.dgx;
@@ -705,12 +704,12 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
 
 // Synchronises the device and reports (then clears) the timeout word of the persistent kernels.
 int persist_status_and_clear() {
-  if (!g_sync) return 0;
-  int st = 0;
+  int* host = persist_status_host();
+  if (!host) return 0;                                   // no whole-sequence kernel has run yet
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(&st, g_sync + P_FLAG_WORDS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (st && hipMemset(g_sync + P_FLAG_WORDS, 0, sizeof(int)) != hipSuccess) return -1;
-  if (g_stamps_on == 1) {
+  const int st = __atomic_load_n(host, __ATOMIC_ACQUIRE);
+  if (st) __atomic_store_n(host, 0, __ATOMIC_RELEASE);
+  if (g_stamps_on == 1 && persist_stamps()) {
     unsigned long long acc[16];
     if (hipMemcpy(acc, persist_stamps(), sizeof(acc), hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "[cvae persist stamps, cycles of block (0,0)] loop-top->wait %llu | wait %llu | load+mfma %llu | reduce %llu | "
@@ -718,7 +717,13 @@ int persist_status_and_clear() {
       if (hipMemset(persist_stamps(), 0, sizeof(acc)) != hipSuccess) return -1;
     }
   }
-  return st;
+  return st ? 1 : 0;
+}
+
+// The same word without synchronising or clearing: 1 as soon as a timed-out kernel's store has landed.
+int persist_status_peek() {
+  int* host = persist_status_host();
+  return host ? (__atomic_load_n(host, __ATOMIC_ACQUIRE) ? 1 : 0) : 0;
 }
 
 }  // namespace cvae

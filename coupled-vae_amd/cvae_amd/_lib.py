@@ -53,6 +53,8 @@ SIGNATURES = {
     'cvae_decoder_forward_n': [I, I, I, I, I, I, L] + [P] * 14,
     'cvae_decoder_backward_n': [I, I, I, I, I, I, L] + [P] * 16,
     'cvae_persist_status': [],
+    'cvae_persist_status_peek': [],
+    'cvae_persist_status_set': [I],
     'cvae_projce_workspace': [L, L, L],
     'cvae_projce_forward': [P, P, P, P, L, I, I, I, I, L, P, P, P, P, P],
     'cvae_projce_backward_workspace': [L, L, L],

@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import dist_utils, ops
+from . import _lib, dist_utils, ops
 from .modules import MODEL_CLASSES
 from .settings import settings
 
@@ -199,7 +199,13 @@ class Trainer(object):
         self.iter_num += 1
         self.model.train(True)
         self.opt.zero_grad()
-        res = self.losses(batch)
+        # every term below is a batch mean: the model may leave its per-row outputs in its own (length-sorted)
+        # processing order (modules.RowOrder) instead of un-permuting each of them
+        keep, settings.restore_row_order = settings.restore_row_order, False
+        try:
+            res = self.losses(batch)
+        finally:
+            settings.restore_row_order = keep
         res['tot'].backward()
         self.opt.gather_grads()
         if self.world > 1:
@@ -208,11 +214,28 @@ class Trainer(object):
             dist_utils.allreduce_mean_(self.opt.grads)
         return res
 
+    def check_kernels(self, sync=False):
+        """Raises CvaeHipError if a whole-sequence recurrent kernel ran out of its bounded in-kernel wait (its
+        results, and everything computed from them, are invalid).  The word lives in host-mapped memory, so the
+        default check costs a host read and no synchronisation: it sees a failure once the failing kernel's store
+        has landed, at the latest one step later; cvae_clip_adam checks the same word on the device and does not
+        apply a step while it is set, so the weights are never touched by a timed-out step.  sync=True
+        synchronises the device first (use it where the host reads results anyway)."""
+        bad = _lib.query('cvae_persist_status') if sync else _lib.query('cvae_persist_status_peek')
+        if bad:
+            if not sync:
+                _lib.query('cvae_persist_status')            # synchronise and clear
+            raise _lib.CvaeHipError(
+                'a whole-sequence recurrent kernel timed out (iteration %d): its blocks were not all resident at once '
+                '-- another kernel shared the GPU (a second process or stream, a profiler).  The optimizer step of the '
+                'affected iteration was NOT applied.  Run alone on the device or set CVAE_PERSISTENT_RNN=0.' % self.iter_num)
+
     def train_step(self, batch):
         """forward + backward (+ gradient all-reduce) + clip + Adam.  Returns the loss dict
         (device scalars: nothing syncs here; read them back in one copy when logging)."""
         res = self.forward_backward(batch)
         self.opt.step()
+        self.check_kernels()
         return res
 
     # ---- evaluation: CV/Experiment.py:1323-1396 ; CC/Experiment.py:538-621
@@ -241,6 +264,7 @@ class Trainer(object):
         if not settings.shard_samples:
             dist_utils.reduce_sums_(acc)
         a = acc.tolist()
+        self.check_kernels(sync=True)
         self.model.train(True)
         return dict(nll=a[0] / a[4], xent=a[1] / a[4], kl=a[2] / a[4], ppl=math.exp(a[0] / a[3]),
                     n=int(a[4])), per_sentence
@@ -256,6 +280,7 @@ class Trainer(object):
         dist_utils.reduce_sums_(acc)
         self.model.train(True)
         a = acc.tolist()
+        self.check_kernels(sync=True)
         return a[0] / max(a[1], 1.0)
 
 

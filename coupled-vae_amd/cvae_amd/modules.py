@@ -44,7 +44,11 @@ class NoiseSource(object):
 
 
 class ReplayNoise(NoiseSource):
-    """Replays named tensors (golden fixtures): dict name -> tensor or list of tensors."""
+    """Replays named tensors (golden fixtures): dict name -> tensor or list of tensors.  The recorded tensors are
+    in the reference's layout (column b = batch row b of the caller); while a RowOrder is active the model
+    processes the batch's rows in another order, so the replayed columns follow it.  (The default source draws
+    i.i.d. values: which row gets which column is immaterial there, so it never permutes.)  The encoders' masks are
+    exempt: the reference draws them in ITS length-sorted layout, which cvae_encoder_forward's mask_rows handles."""
 
     def __init__(self, table):
         self.table = {k: (list(v) if isinstance(v, (list, tuple)) else [v]) for k, v in table.items()}
@@ -56,6 +60,8 @@ class ReplayNoise(NoiseSource):
         if t.dim() == len(shape) - 1 and shape[0] == 1:      # a (1,B,Z) draw recorded as (B,Z)
             t = t.unsqueeze(0)
         assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
+        if _row_order is not None and not name.endswith('enc_drop'):
+            t = t.index_select(1, _row_order.s_idx)          # every per-row draw has its rows in dim 1
         return t
 
     def dropout_mask(self, shape, p, device, name):
@@ -69,6 +75,57 @@ class ReplayNoise(NoiseSource):
 
 
 _noise = NoiseSource()
+_row_order = None        # the RowOrder of the forward pass in progress (None: rows in the caller's order)
+
+
+class RowOrder(object):
+    """Training forward passes process the batch's rows in order of non-increasing length (stable: the order of
+    utils.sort_resort, CV/utils/utils.py:18-21, computed on the device).  Rows are independent and every loss term
+    is a per-row value, so nothing changes numerically; what it buys: rows still inside their sentence at step t
+    are a prefix, so the backward recurrence exchanges, and the weight-gradient products visit, live rows only,
+    and the encoder's dropout mask (drawn by the reference in exactly this order, encoder.py:50-56) needs no
+    indirection.  Per-row outputs are returned in the caller's order (`back`) unless settings.restore_row_order
+    is off."""
+
+    def __init__(self, length):
+        self.s_idx, self.res_idx = ops.sort_resort(length)
+        self.restore = settings.restore_row_order
+        self._targets = {}
+
+    def take(self, *ts):
+        out = tuple(t.index_select(0, self.s_idx) for t in ts)
+        return out if len(out) > 1 else out[0]
+
+    def back(self, t):
+        return t.index_select(0, self.res_idx) if self.restore else t
+
+    def targets(self, gts):
+        """The caller's (B,T) targets in the processing order (shared by the two decoders' losses)."""
+        key = (gts.data_ptr(), tuple(gts.shape))
+        if key not in self._targets:
+            self._targets = {key: gts.index_select(0, self.s_idx)}
+        return self._targets[key]
+
+
+class _rows_in(object):
+    """with _rows_in(order): the replayed noise follows `order` inside the block."""
+
+    def __init__(self, order):
+        self.order = order
+
+    def __enter__(self):
+        global _row_order
+        self.prev, _row_order = _row_order, self.order
+        return self.order
+
+    def __exit__(self, *exc):
+        global _row_order
+        _row_order = self.prev
+        return False
+
+
+def _train_order(length):
+    return RowOrder(length) if (settings.sort_train_rows and length.numel() > 1) else None
 
 
 def set_noise_source(src):
@@ -90,8 +147,9 @@ class LazyLogits(object):
     `final` states plus the ToVocab parameters.  SeqLoss consumes it through the fused
     projection + cross-entropy kernel; `.materialize()` builds the real tensor on demand."""
 
-    def __init__(self, final, weight, bias, n_sent):
+    def __init__(self, final, weight, bias, n_sent, order=None):
         self.final, self.weight, self.bias, self.n_sent = final, weight, bias, n_sent
+        self.order = order            # RowOrder the rows of `final` are in (None: the caller's order)
 
     @property
     def shape(self):
@@ -99,7 +157,8 @@ class LazyLogits(object):
         return torch.Size([R, T, self.weight.shape[0]])
 
     def materialize(self):
-        return ops.logits_bt(self.final.detach(), self.weight.detach(), self.bias.detach())
+        out = ops.logits_bt(self.final.detach(), self.weight.detach(), self.bias.detach())
+        return out if self.order is None else out.index_select(0, self.order.res_idx)
 
 
 # --------------------------------------------------------------------------- SeqLoss
@@ -118,7 +177,12 @@ class SeqLoss(nn.Module):
         if logits.shape[0] == 0:
             return torch.zeros((), device=gts.device)
         assert logits.shape[:-1] == gts.shape or logits.shape[0] % gts.shape[0] == 0
-        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, gts[:logits.n_sent], self.pad)
+        tgt = gts[:logits.n_sent]
+        if logits.order is not None:
+            tgt = logits.order.targets(tgt)
+        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad)
+        if logits.order is not None:
+            sent = logits.order.back(sent)
         if keep_batch:
             return sent
         return sent.sum() / (gts != self.pad).sum().to(sent.dtype)
@@ -143,35 +207,39 @@ class Encoder(nn.Module):
         else:
             self.GRU = nn.GRU(**kw)
 
-    def _operands(self, bare, length, noise_name):
+    def _operands(self, bare, length, noise_name, mask_rows='sort'):
+        """mask_rows: 'sort' = column of the dropout mask that row b uses, from this batch's own length order (the
+        reference draws the mask after sorting by length, encoder.py:50-56); None = the rows already are in that
+        order; or the (B,) int64 column vector itself."""
         rnn = self.LSTM if self.use_lstm else self.GRU
         w = _rnn_weights(rnn) + _rnn_weights(rnn, True)
         B, L = bare.shape
-        mask = mask_rows = None
+        mask = None
         if self.training:
-            # the reference draws the mask after sorting by length (encoder.py:50-56)
             mask = _noise.dropout_mask((L, B, self.emb_dim), self.dropout, bare.device, noise_name)
-            if mask is not None:
-                _, mask_rows = ops.sort_resort(length)
+        if mask is None:
+            mask_rows = None
+        elif isinstance(mask_rows, str):
+            _, mask_rows = ops.sort_resort(length)
         return w, mask, mask_rows
 
-    def last_flat(self, bare, length, noise_name='enc_drop'):
+    def last_flat(self, bare, length, noise_name='enc_drop', mask_rows='sort'):
         """(B, 2H) = [h_fwd | h_bwd]."""
-        w, mask, mask_rows = self._operands(bare, length, noise_name)
+        w, mask, mask_rows = self._operands(bare, length, noise_name, mask_rows)
         cell = ops.LSTM if self.use_lstm else ops.GRU
         return ops.encoder(cell, bare, length, mask, mask_rows, self.Embedding.weight, w)
 
     @staticmethod
-    def last_flat_pair(enc_a, bare_a, len_a, noise_a, enc_b, bare_b, len_b, noise_b):
+    def last_flat_pair(enc_a, bare_a, len_a, noise_a, enc_b, bare_b, len_b, noise_b, rows_a='sort', rows_b='sort'):
         """Both encoders of the dialogue model in the same launches when they share the embedding and shape;
         otherwise one after the other.  The noise tape is consumed in the same order either way."""
         same = (enc_a.Embedding is enc_b.Embedding and enc_a.hid_dim == enc_b.hid_dim
                 and enc_a.use_lstm == enc_b.use_lstm and bare_a.shape[0] == bare_b.shape[0]
                 and settings.pair_encoders)
         if not same:
-            return enc_a.last_flat(bare_a, len_a, noise_a), enc_b.last_flat(bare_b, len_b, noise_b)
-        w_a, mask_a, rows_a = enc_a._operands(bare_a, len_a, noise_a)
-        w_b, mask_b, rows_b = enc_b._operands(bare_b, len_b, noise_b)
+            return enc_a.last_flat(bare_a, len_a, noise_a, rows_a), enc_b.last_flat(bare_b, len_b, noise_b, rows_b)
+        w_a, mask_a, rows_a = enc_a._operands(bare_a, len_a, noise_a, rows_a)
+        w_b, mask_b, rows_b = enc_b._operands(bare_b, len_b, noise_b, rows_b)
         cell = ops.LSTM if enc_a.use_lstm else ops.GRU
         return ops.encoder_pair(cell, bare_a, len_a, mask_a, rows_a, w_a, bare_b, len_b, mask_b, rows_b, w_b,
                                 enc_a.Embedding.weight)
@@ -244,17 +312,17 @@ class Decoder(nn.Module):
         return ops.decoder_beam(cell, init_input, helper[:, 0], self.max_len, self.beam_size, self.Embedding.weight,
                                 w, self.ToVocab.weight, self.ToVocab.bias, mask_id=3, return_nll=return_nll)
 
-    def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None):
+    def forward(self, init_states, init_input, helper, test_lm=False, _noise_prefix='dec', _n_sent=None, _order=None):
         if not (self.training or test_lm):
             ids = self.beam(init_input, helper) if self.beam_size > 1 else self.greedy(init_input, helper)
             # the reference's return format: per sentence, a list of max_len tensors of shape (1,)
             return [[ids[b, t:t + 1] for t in range(ids.shape[1])] for b in range(ids.shape[0])]
         n_sent = helper.shape[0] if _n_sent is None else _n_sent
         final = self.final_states(init_input, helper[:n_sent], self.training and not test_lm, _noise_prefix)
-        return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, n_sent)
+        return LazyLogits(final, self.ToVocab.weight, self.ToVocab.bias, n_sent, _order)
 
 
-def decode_pair(dec_a, dec_b, init_a, init_b, helper):
+def decode_pair(dec_a, dec_b, init_a, init_b, helper, order=None):
     """Decoder and DecoderCouple on the same `helper` in lock-step (training): same draws, in the
     reference's order (dec in/out masks, then decc in/out masks), one launch per timestep for both."""
     R = init_a.shape[0]
@@ -269,8 +337,8 @@ def decode_pair(dec_a, dec_b, init_a, init_b, helper):
         specs.append((init, mi, mo, w))
     cell = ops.LSTM if dec_a.use_lstm else ops.GRU
     fa, fb = ops.decoder_pair(cell, helper, dec_a.Embedding.weight, specs)
-    return (LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B),
-            LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B))
+    return (LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B, order),
+            LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B, order))
 
 
 def to_init(seq, x):
@@ -451,11 +519,18 @@ class VAE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        last = self.Encoder.last_flat(bare, sent_len)
-        dist, z = self.PosteriorGaussian(last)
-        init = to_init(self.Decoder.toInit, z)
-        logits = self.Decoder(None, init, go)
-        return logits, dist, z, None
+        ro = _train_order(sent_len)
+        if ro is None:
+            last = self.Encoder.last_flat(bare, sent_len)
+            dist, z = self.PosteriorGaussian(last)
+            return self.Decoder(None, to_init(self.Decoder.toInit, z), go), dist, z, None
+        go, bare, sent_len = ro.take(go, bare, sent_len)
+        with _rows_in(ro):
+            last = self.Encoder.last_flat(bare, sent_len, mask_rows=None)
+            dist, z = self.PosteriorGaussian(last)
+            logits = self.Decoder(None, to_init(self.Decoder.toInit, z), go, _order=ro)
+        dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
+        return logits, dist, ro.back(z), None
 
 
 class DAE(_TextBase):
@@ -471,8 +546,8 @@ class DAE(_TextBase):
         self.Decoder = Decoder(with_init=True, **self._dec_kwargs(decoder_emb))
         self.criterionSeq = SeqLoss(voc_size=self.voc_size, pad=pad_id, end=None, unk=None)
 
-    def _latent(self, bare, sent_len):
-        last = self.Encoder.last_flat(bare, sent_len)
+    def _latent(self, bare, sent_len, mask_rows='sort'):
+        last = self.Encoder.last_flat(bare, sent_len, mask_rows=mask_rows)
         return ops.linear(last, self.toLatent.weight, self.toLatent.bias, ops.ACT_NONE)
 
     def forward(self, go, sent_len=None, bare=None):
@@ -480,8 +555,15 @@ class DAE(_TextBase):
             latent = _noise.normal((go.shape[0], self.latent_dim), go.device, 'prior_z')
             with torch.no_grad():
                 return self.Decoder(None, to_init(self.Decoder.toInit, latent), go)
-        latent = self._latent(bare, sent_len)
-        return self.Decoder(None, to_init(self.Decoder.toInit, latent), go), latent
+        ro = _train_order(sent_len)
+        if ro is None:
+            latent = self._latent(bare, sent_len)
+            return self.Decoder(None, to_init(self.Decoder.toInit, latent), go), latent
+        go, bare, sent_len = ro.take(go, bare, sent_len)
+        with _rows_in(ro):
+            latent = self._latent(bare, sent_len, mask_rows=None)
+            logits = self.Decoder(None, to_init(self.Decoder.toInit, latent), go, _order=ro)
+        return logits, ro.back(latent)
 
     def test_lm(self, go, sent_len, bare, eos, n_sample):
         """dae.py test_lm: one deterministic decode; nll = kl = +inf by the reference's definition."""
@@ -582,14 +664,21 @@ class VAE_COUPLE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        last = self.Encoder.last_flat(bare, sent_len)
-        dist, z = self.PosteriorGaussian(last)
-        # the coupled head only uses its mean, but the reference still draws its noise (vae_couple.py:721,801)
-        mu_c, _ = self.PosteriorGaussianCouple.params(last, need_sigma=False)
-        _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
-        init = to_init(self.toInit, z)
-        init_c = to_init(self.toInitCouple, mu_c)
-        logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, go)
+        ro = _train_order(sent_len)
+        if ro is not None:
+            go, bare, sent_len = ro.take(go, bare, sent_len)
+        with _rows_in(ro):
+            last = self.Encoder.last_flat(bare, sent_len, mask_rows='sort' if ro is None else None)
+            dist, z = self.PosteriorGaussian(last)
+            # the coupled head only uses its mean, but the reference still draws its noise (vae_couple.py:721,801)
+            mu_c, _ = self.PosteriorGaussianCouple.params(last, need_sigma=False)
+            _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
+            init = to_init(self.toInit, z)
+            init_c = to_init(self.toInitCouple, mu_c)
+            logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, go, ro)
+        if ro is not None:
+            dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
+            z, init, init_c = ro.back(z), ro.back(init), ro.back(init_c)
         return logits, dist, z, None, logits_c, init, init_c
 
 
@@ -599,11 +688,23 @@ class _DialogBase(nn.Module):
     _dec_kwargs = _TextBase._dec_kwargs
     _to_init_seq = _TextBase._to_init_seq
 
-    def _encode(self, post_bare, post_len, resp_bare, resp_len):
+    def _encode(self, post_bare, post_len, resp_bare, resp_len, rows_post='sort', rows_resp='sort'):
         post, resp = Encoder.last_flat_pair(self.PostEncoder, post_bare, post_len, 'post_enc_drop',
-                                            self.RespEncoder, resp_bare, resp_len, 'resp_enc_drop')
+                                            self.RespEncoder, resp_bare, resp_len, 'resp_enc_drop', rows_post, rows_resp)
         post_repr = ops.linear(post, self.PostRepr.weight, self.PostRepr.bias)
         return post, post_repr, torch.cat([resp, post], dim=1)
+
+    def _train_rows(self, post_bare, post_len, resp_go, resp_len, resp_bare):
+        """Rows in order of non-increasing RESPONSE length (the decoders' sequences).  The response encoder's mask
+        is then in its own order; the post encoder's mask columns follow the reference's sort of the ORIGINAL
+        rows by post length, looked up through the row order."""
+        ro = _train_order(resp_len)
+        if ro is None:
+            return None, (post_bare, post_len, resp_go, resp_len, resp_bare), 'sort', 'sort'
+        rows_post = 'sort'
+        if self.training and self.dropout > 0.0:
+            rows_post = ops.sort_resort(post_len)[1].index_select(0, ro.s_idx)
+        return ro, ro.take(post_bare, post_len, resp_go, resp_len, resp_bare), rows_post, None
 
     def sample_from_prior(self, post_bare, post_len, resp_go):
         """CC/Modules/vae_couple.py:369-397 / vae.py:157-184: encode the post, z ~ prior network, decode
@@ -648,11 +749,18 @@ class CVAE(_DialogBase):
     def forward(self, post_bare, post_len, resp_go, resp_len, resp_bare):
         if not self.training:
             raise NotImplementedError()
-        post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len)
-        prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
-        dist, z = self.PosteriorGaussian(both)
-        init = to_init(self.Decoder.toInit, z) + post_repr
-        return self.Decoder(None, init, resp_go), prior, dist
+        ro, (post_bare, post_len, resp_go, resp_len, resp_bare), rows_post, rows_resp = self._train_rows(
+            post_bare, post_len, resp_go, resp_len, resp_bare)
+        with _rows_in(ro):
+            post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len, rows_post, rows_resp)
+            prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
+            dist, z = self.PosteriorGaussian(both)
+            init = to_init(self.Decoder.toInit, z) + post_repr
+            logits = self.Decoder(None, init, resp_go, _order=ro)
+        if ro is not None:
+            prior = torch.distributions.Normal(ro.back(prior.loc), ro.back(prior.scale), validate_args=False)
+            dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
+        return logits, prior, dist
 
 
 class CVAE_COUPLE(_DialogBase):
@@ -681,14 +789,21 @@ class CVAE_COUPLE(_DialogBase):
     def forward(self, post_bare, post_len, resp_go, resp_len, resp_bare):
         if not self.training:
             raise NotImplementedError()
-        post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len)
-        prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
-        dist, z = self.PosteriorGaussian(both)
-        mu_c, _ = self.PosteriorGaussianCouple.params(both, need_sigma=False)
-        _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
-        init = to_init(self.toInit, z) + post_repr
-        init_c = to_init(self.toInitCouple, mu_c) + post_repr
-        logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, resp_go)
+        ro, (post_bare, post_len, resp_go, resp_len, resp_bare), rows_post, rows_resp = self._train_rows(
+            post_bare, post_len, resp_go, resp_len, resp_bare)
+        with _rows_in(ro):
+            post, post_repr, both = self._encode(post_bare, post_len, resp_bare, resp_len, rows_post, rows_resp)
+            prior, _ = self.PriorGaussian(post, _noise_name='eps_prior', _sample=False)
+            dist, z = self.PosteriorGaussian(both)
+            mu_c, _ = self.PosteriorGaussianCouple.params(both, need_sigma=False)
+            _noise.normal((1,) + tuple(mu_c.shape), mu_c.device, 'eps_couple')
+            init = to_init(self.toInit, z) + post_repr
+            init_c = to_init(self.toInitCouple, mu_c) + post_repr
+            logits, logits_c = decode_pair(self.Decoder, self.DecoderCouple, init, init_c, resp_go, ro)
+        if ro is not None:
+            prior = torch.distributions.Normal(ro.back(prior.loc), ro.back(prior.scale), validate_args=False)
+            dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
+            init, init_c = ro.back(init), ro.back(init_c)
         return logits, prior, dist, logits_c, init, init_c
 
 

@@ -11,6 +11,10 @@ class _Settings(object):
     ce_save_logits_max_bytes = 8 << 30   # per call; above it the backward recomputes
     shard_samples = False     # multi-GPU IW eval: shard the K samples of every sentence over ranks (dist_utils)
     truncate_eval = True      # cut T to max(len)+1 in test_lm (exact: pad targets weigh 0)
+    sort_train_rows = True    # training forward: process the batch's rows in order of non-increasing length
+    #                           (modules.RowOrder; per-row outputs come back in the caller's order)
+    restore_row_order = True  # False: per-row outputs of forward() stay in the sorted order (callers that only
+    #                           take batch means, i.e. harness.Trainer, save the un-permute launches)
 
 
 settings = _Settings()

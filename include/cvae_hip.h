@@ -11,7 +11,10 @@
  *  - `stream` is a hipStream_t (NULL = default stream); all work is enqueued, nothing syncs.
  *  - return 0 on success, negative on error; cvae_last_error() returns the message
  *    (thread-local).  Shape / pointer preconditions are checked on the host before launch.
- *  - nothing here allocates: workspaces are passed in by the caller.
+ *  - workspaces are passed in by the caller.  Exceptions owned by the library, one set per (device, stream),
+ *    allocated at their first use and regrown only when a larger shape arrives (warm-up; steady-state calls
+ *    allocate nothing): the whole-sequence recurrent kernels' flag words and partial-gradient exchange, the
+ *    split-K products' partial-sum slabs, and the live-row index lists of the backward passes.
  *  - cell: 0 = GRU (gate rows r,z,n), 1 = LSTM (i,f,g,o), PyTorch equations and layouts.
  *    G = 3 or 4 below.
  */
@@ -311,6 +314,13 @@ int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* t
  * recurrent kernels: 0 = every in-kernel wait completed; 1 = a bounded spin ran out (results of
  * that call are invalid).  No counterpart in the reference (torch's cuDNN RNN has no such state). */
 int cvae_persist_status(void);
+/* The same word read without synchronising or clearing (it lives in host-mapped pinned memory and the kernel
+ * that timed out writes it directly): 1 as soon as that store has landed.  Cheap enough to call every training
+ * step.  cvae_clip_adam takes its own look at the word on the device and leaves the parameters untouched while
+ * it is set, so a timed-out step is never applied; clear it with cvae_persist_status(). */
+int cvae_persist_status_peek(void);
+/* Test aid: writes the word from the host (what a timed-out kernel would do), to exercise the callers' handling. */
+int cvae_persist_status_set(int value);
 int cvae_sum_time(const float* x, int T, int R, float* out, void* stream);       /* out[r] = sum_t x[t,r] */
 int cvae_axpy(const float* x, float a, int64_t n, float* y, void* stream);       /* y += a*x */
 

@@ -166,3 +166,29 @@ def test_resident_batches_back_to_back_behind_a_long_kernel(dev):
     for w, g in zip(want, got):
         for x, y in zip(w, g):
             assert torch.equal(x, y)
+
+
+def test_persist_timeout_is_loud_and_the_step_is_not_applied(dev):
+    """A timed-out whole-sequence kernel raises the status word (host-mapped).  With the word set -- here from the
+    host, as the kernel would -- Trainer.train_step must raise, cvae_clip_adam must leave every parameter as it was,
+    and cvae_persist_status must report and clear it; the next step then runs and updates the weights."""
+    from cvae_amd import data, harness, _lib
+    hp = harness.HParams(model='vae-couple', cell='gru', V=300, E=24, H=128, Z=8)
+    tr = harness.Trainer(hp, dev, seed=1)
+    c = data.Corpus(data.synthetic_sentences(16, hp.V, 2.5, 0.4, 20, seed=3))
+    batch = harness.text_batch(c, range(16), dev)
+    tr.train_step(batch)
+    before = tr.opt.params.clone()
+    _lib.call('cvae_persist_status_set', 1)
+    try:
+        assert _lib.query('cvae_persist_status_peek') == 1
+        with pytest.raises(_lib.CvaeHipError, match='timed out'):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        assert torch.equal(tr.opt.params, before), 'a step was applied although the status word was set'
+    finally:
+        _lib.query('cvae_persist_status')                 # report + clear (check_kernels has already done so)
+    assert _lib.query('cvae_persist_status_peek') == 0
+    tr.train_step(batch)
+    torch.cuda.synchronize()
+    assert not torch.equal(tr.opt.params, before)
