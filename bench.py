@@ -36,7 +36,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
            3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
-           6: ('rnn_fwd_persist_kernel', 'mfma'), 7: ('rnn_bwd_persist_kernel', 'mfma')}
+           6: ('rnn_fwd_persist_kernel', 'mfma'), 7: ('rnn_bwd_persist_kernel', 'mfma'),
+           8: ('rnn_large_step_kernel', 'mfma'), 9: ('gemm_nt_kernel', 'mfma')}
 
 
 def parse():
@@ -50,6 +51,7 @@ def parse():
     ap.add_argument('--iw-batches', type=int, default=2, help='evaluation batches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-iw', action='store_true')
+    ap.add_argument('--no-ptb', action='store_true', help='skip the PTB-shape LSTM sub-record')
     ap.add_argument('--iw-shard', default='sentences', choices=['sentences', 'samples'],
                     help='N > 1: shard evaluation batches over ranks (weak scaling, default) or the K samples of '
                          'every sentence (same batches on every rank, all-gather of the cross-entropy rows)')
@@ -90,17 +92,21 @@ def profile_read(lib):
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench,
+    (profiles/r02_pmc_hbm_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from
     inside this process, so the figure is the recorded one for the same workload, or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_summary.json')
-    if kernel != 'ce_core_kernel' or not os.path.exists(path):
+    if kernel != 'ce_core_kernel':
         return None
-    try:
-        rec = json.load(open(path))['ce_core_forward_eval_launch']
-        return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
-    except (KeyError, ValueError):
-        return None
+    for name in ('r02_pmc_hbm_summary.json', 'r01_pmc_hbm_summary.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            rec = json.load(open(path))['ce_core_forward_eval_launch']
+            if 'false, true, false' not in rec.get('kernel', 'false, true, false'):
+                continue
+            return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def roofline_of(prof, region):
@@ -119,55 +125,137 @@ def roofline_of(prof, region):
                 work_per_launch=rec['work'] / rec['launches'])
 
 
+def host_cores():
+    """(physical cores of socket 0, threads this process may use).  SURVEY 8d: the CPU baseline runs on the physical
+    cores of one socket; on the GPU box the job's CPU share is smaller (OMP_NUM_THREADS), which caps it."""
+    cores = set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = int(line.split(':')[1])
+            elif line.startswith('core id'):
+                core = int(line.split(':')[1])
+            elif not line.strip():
+                if phys == 0 and core is not None:
+                    cores.add(core)
+                phys = core = None
+    except OSError:
+        pass
+    socket = len(cores) or (os.cpu_count() or 1)
+    share = socket
+    try:
+        share = min(share, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    if os.environ.get('OMP_NUM_THREADS', '').isdigit():
+        share = min(share, int(os.environ['OMP_NUM_THREADS']))
+    return socket, max(share, 1)
+
+
 def cpu_baseline(args, shape):
-    """The oracle ("port": CPU restatement proven equal to the reference, tests/test_oracle_golden.py)
-    timed on this host's cores on a bounded sample of the same workload."""
+    """The oracle ("port": CPU restatement proven equal to the reference, tests/test_oracle_golden.py) timed on
+    this host's cores on a bounded sample of the same workload, by SURVEY 8d's protocol: 3 warm-up + 10 timed
+    training steps on the same synthetic batches (reference row order), threads = the physical cores of one
+    socket (capped by the job's CPU share); IW-NLL timed on one full batch of 32 sentences at a stated K."""
     from oracle import cvae_oracle as O
-    n_thr = min(16, os.cpu_count() or 1)
+    socket_cores, n_thr = host_cores()
     torch.set_num_threads(n_thr)
     model, cell = 'vae-couple', args.cell
     P = O.tie_aliases(O.init_params(model, cell, shape['V'], shape['E'], shape['H'], shape['Z'], seed=0))
-    B = 32
-    sents = O.synthetic_sentences(B, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=0)
-    bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch(sents, 200, truncate=True))
-    batch = dict(bare=bare, go=go, eos=eos, len=ln)
-    L, T = bare.shape[1], go.shape[1]
+    B, n_warm, n_steps = 32, 3, 10
+    sents = O.synthetic_sentences(B * (n_warm + n_steps), shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000)
     g = torch.Generator().manual_seed(0)
 
     def drop(*s):
         return (torch.rand(*s, generator=g) > 0.2).float() / 0.8
 
     Hd, E = 2 * shape['H'], shape['E']
-    noise = dict(enc_drop=drop(L, B, E), eps=torch.randn(B, shape['Z'], generator=g),
-                 dec_in_drop=drop(T, B, 2 * E), dec_out_drop=drop(T, B, Hd),
-                 decc_in_drop=drop(T, B, 2 * E), decc_out_drop=drop(T, B, Hd))
     cfg = dict(latent_dim=shape['Z'], lambda_kl=0.5, lambda_couple=0.1, lambda_seq_couple=1.0, euclidean_dist=False)
     keys = [k for k in P.keys() if not k.startswith('BoW') and 'PosteriorGaussianCouple.toSigma' not in k]
     state = {}
-    O.train_step(P, model, cell, batch, noise, cfg, state, keys)          # warm-up
-    n_steps = 2
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
+    tokens, dt = 0, 0.0
+    for i in range(n_warm + n_steps):
+        bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch(sents[i * B:(i + 1) * B], 200, truncate=True))
+        batch = dict(bare=bare, go=go, eos=eos, len=ln)
+        L, T = bare.shape[1], go.shape[1]
+        noise = dict(enc_drop=drop(L, B, E), eps=torch.randn(B, shape['Z'], generator=g),
+                     dec_in_drop=drop(T, B, 2 * E), dec_out_drop=drop(T, B, Hd),
+                     decc_in_drop=drop(T, B, 2 * E), decc_out_drop=drop(T, B, Hd))
+        t0 = time.perf_counter()
         O.train_step(P, model, cell, batch, noise, cfg, state, keys)
-    dt = (time.perf_counter() - t0) / n_steps
-    tokens = int((ln + 1).sum())
-    # IW-NLL sample: 4 sentences x 10 samples, scaled to sentences/s at the configured K
-    Bs, Ks = 4, 10
-    sb = dict(bare=bare[:Bs], go=go[:Bs], eos=eos[:Bs], len=ln[:Bs])
-    m = int(ln[:Bs].max())
-    sb = dict(bare=sb['bare'][:, :m], go=sb['go'][:, :m + 1], eos=sb['eos'][:, :m + 1], len=sb['len'])
-    eps = torch.randn(Ks, Bs, shape['Z'], generator=g)
+        if i >= n_warm:
+            dt += time.perf_counter() - t0
+            tokens += int((ln + 1).sum())
+    # IW-NLL: one full batch of 32 sentences, K = the reference's validation setting (10; Experiment.py:1330-1335)
+    Ks = 10
+    bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch(sents[:B], 200, truncate=True))
+    sb = dict(bare=bare, go=go, eos=eos, len=ln)
+    eps = torch.randn(Ks, B, shape['Z'], generator=g)
     for pp in {id(v): v for v in P.values()}.values():
         pp.requires_grad_(False)
     t0 = time.perf_counter()
     with torch.no_grad():
         O.iw_nll(P, model, cell, sb, eps)
     dt_iw = time.perf_counter() - t0
-    sent_per_s = Bs / (dt_iw * args.iw_samples / Ks)
-    return dict(value=round(tokens / dt, 1), unit='tokens/s', cores=n_thr, kind='port',
-                sample='%d train steps (batch 32, same shape, after 1 warm-up) of the CPU oracle; IW-NLL: %d sentences x '
-                       '%d samples, linearly scaled to K=%d' % (n_steps, Bs, Ks, args.iw_samples),
-                iw_nll_sentences_per_s=round(sent_per_s, 4), ms_per_step=round(dt * 1e3, 1))
+    return dict(value=round(tokens / dt, 1), unit='tokens/s', cores=n_thr, socket_physical_cores=socket_cores,
+                kind='port',
+                sample='%d timed train steps after %d warm-up (batch 32, same shape and length distribution, reference '
+                       'row order) of the CPU oracle on %d threads; IW-NLL: one batch of %d sentences at K=%d, measured '
+                       '(iw_nll_sentences_per_s_K%d); the K=%d figure is that value x %d/%d (the cost is linear in K)'
+                       % (n_steps, n_warm, n_thr, B, Ks, Ks, args.iw_samples, Ks, args.iw_samples),
+                ms_per_step=round(dt / n_steps * 1e3, 1),
+                **{'iw_nll_sentences_per_s_K%d' % Ks: round(B / dt_iw, 4),
+                   'iw_nll_sentences_per_s': round(B / dt_iw * Ks / args.iw_samples, 4)})
+
+
+def rnn_live_flops(hp, batches):
+    """Algorithmic FLOPs of the recurrent products over LIVE (row, step) pairs only: the encoder's two directions
+    run len steps per sentence, each decoder the prefix step + len+1 target steps.  (The library's own figure for
+    the whole-sequence kernels counts the padded T*R pairs of the launch.)  Same for forward and backward."""
+    G = 3 if hp.cell == 'gru' else 4
+    H, Hd = hp.H, 2 * hp.H
+    nd = 2 if hp.is_couple() else 1
+    tot = 0.0
+    for b in batches:
+        ln = b['len'].double()
+        tot += 2.0 * G * H * H * 2 * float(ln.sum()) + 2.0 * G * Hd * Hd * nd * float((ln + 2).sum())
+    return tot
+
+
+def run_training(tr, batches, tokens, args, world, dev, rank):
+    """W warm-up + K timed steps; returns (seconds for the K steps, tokens/s of the whole job)."""
+    from cvae_amd import _lib
+    for i in range(args.warmup):
+        tr.train_step(batches[i])
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        tr.train_step(batches[i])
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    if _lib.query('cvae_persist_status') != 0:
+        raise _lib.CvaeHipError('a whole-sequence recurrent kernel timed out inside the timed region: no figure')
+    tok = torch.tensor([float(sum(tokens[args.warmup:args.warmup + args.steps]))], dtype=torch.float64, device=dev)
+    if world > 1:
+        if dist.get_backend() == 'gloo':
+            tok = tok.cpu()
+        dist.all_reduce(tok)
+    return dt, float(tok.item()) / dt
+
+
+def run_iw(tr, data, harness, shape, B, n_batches, K, by_samples, world, dev, rank, seed=5000):
+    ev = data.Corpus(data.synthetic_sentences(B * (n_batches + 1), shape['V'], shape['mu'], shape['sigma'],
+                                              shape['cap'], seed=seed + (0 if by_samples else rank)))
+    ebatches = [harness.text_batch(ev, range(i * B, (i + 1) * B), dev, truncate=False) for i in range(n_batches + 1)]
+    tr.iw_eval(ebatches[:1], K)                       # warm-up
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    metrics, _ = tr.iw_eval(ebatches[1:], K)
+    barrier_sync(world)
+    dt_iw = max_over_ranks(time.perf_counter() - t0, world, dev)
+    return ebatches, dict(value=round(metrics['n'] / dt_iw, 3), unit='sentences/s', n_sample=K, sentences=metrics['n'],
+                          seconds=round(dt_iw, 4))
 
 
 def main():
@@ -207,28 +295,14 @@ def main():
     sents = data.synthetic_sentences(B * n_batches, shape['V'], shape['mu'], shape['sigma'], shape['cap'],
                                      seed=1000 + rank)
     corpus = data.Corpus(sents)
-    # rows of a batch in order of non-increasing length (same sentences; the loss is a batch mean): the
-    # backward recurrence then exchanges only the rows still inside their sentence
-    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=True) for i in range(n_batches)]
+    # rows in the corpus' (random) order, as the reference's shuffling DataLoader hands them over; the product
+    # orders a batch's rows by length itself (modules.RowOrder)
+    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev) for i in range(n_batches)]
     tokens = [corpus.n_tokens(range(i * B, (i + 1) * B)) for i in range(n_batches)]
     torch.manual_seed(1234 + rank)                 # dropout / eps streams differ per rank
 
     log(rank, 'training: %d warm-up + %d timed steps' % (args.warmup, args.steps))
-    for i in range(args.warmup):
-        tr.train_step(batches[i])
-    barrier_sync(world)
-    log(rank, 'warm-up done')
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        tr.train_step(batches[i])
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
-    tok = torch.tensor([float(sum(tokens[args.warmup:args.warmup + args.steps]))], dtype=torch.float64, device=dev)
-    if world > 1:
-        if dist.get_backend() == 'gloo':
-            tok = tok.cpu()
-        dist.all_reduce(tok)
-    train_tok_s = float(tok.item()) / dt
+    dt, train_tok_s = run_training(tr, batches, tokens, args, world, dev, rank)
     log(rank, 'training done: %.3f ms/step' % (dt / max(args.steps, 1) * 1e3))
 
     # ---- informational: the same corpus with length-bucketed batches from the device-resident corpus
@@ -260,20 +334,31 @@ def main():
     if not args.no_iw:
         by_samples = args.iw_shard == 'samples' and world > 1
         settings.shard_samples = by_samples
-        ev = data.Corpus(data.synthetic_sentences(B * (args.iw_batches + 1), shape['V'], shape['mu'], shape['sigma'],
-                                                  shape['cap'], seed=5000 + (0 if by_samples else rank)))
-        ebatches = [harness.text_batch(ev, range(i * B, (i + 1) * B), dev, truncate=False)
-                    for i in range(args.iw_batches + 1)]
         log(rank, 'IW-NLL: K=%d, %d batches (+1 warm-up), shard=%s' % (args.iw_samples, args.iw_batches, args.iw_shard))
-        tr.iw_eval(ebatches[:1], args.iw_samples)                       # warm-up
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        metrics, _ = tr.iw_eval(ebatches[1:], args.iw_samples)
-        barrier_sync(world)
-        dt_iw = max_over_ranks(time.perf_counter() - t0, world, dev)
-        iw = dict(value=round(metrics['n'] / dt_iw, 3), unit='sentences/s', n_sample=args.iw_samples,
-                  shard=args.iw_shard if world > 1 else 'none',
-                  sentences=metrics['n'], seconds=round(dt_iw, 4))
+        ebatches, iw = run_iw(tr, data, harness, shape, B, args.iw_batches, args.iw_samples, by_samples, world, dev, rank)
+        iw['shard'] = args.iw_shard if world > 1 else 'none'
+
+    # ---- the shape BASELINE.json's metric names: PTB-shape LSTM-VAE with coupling (configs[0] on the GPU), batch 32,
+    # train step + IW-NLL at the reference's test setting K = 100 (Experiment.py:1330-1335)
+    ptb = None
+    if args.workload != 'ptb' and not args.no_ptb:
+        ps = data.SHAPES['ptb']
+        php = harness.HParams(model='vae-couple', cell='lstm', V=ps['V'], E=ps['E'], H=ps['H'], Z=ps['Z'], annealing_start=2000)
+        ptr = harness.Trainer(php, dev, seed=0)
+        ptr.iter_num = 20000
+        pc = data.Corpus(data.synthetic_sentences(B * n_batches, ps['V'], ps['mu'], ps['sigma'], ps['cap'], seed=2000 + rank))
+        pb = [harness.text_batch(pc, range(i * B, (i + 1) * B), dev) for i in range(n_batches)]
+        ptok = [pc.n_tokens(range(i * B, (i + 1) * B)) for i in range(n_batches)]
+        pdt, ptoks = run_training(ptr, pb, ptok, args, world, dev, rank)
+        ptb = dict(workload='PTB-shape Coupled-VAE (vae-couple, lstm): V=%d E=%d H=%d Z=%d, batch %d per GPU, lengths '
+                            'lognormal(%.1f,%.2f) cap %d' % (ps['V'], ps['E'], ps['H'], ps['Z'], B, ps['mu'], ps['sigma'], ps['cap']),
+                   value=round(ptoks, 1), unit='tokens/s', ms_per_step=round(pdt / max(args.steps, 1) * 1e3, 3))
+        if not args.no_iw:
+            settings.shard_samples = False
+            _, ptb['iw_nll'] = run_iw(ptr, data, harness, ps, B, 8, 100, False, world, dev, rank, seed=6000)
+            settings.shard_samples = args.iw_shard == 'samples' and world > 1
+        log(rank, 'PTB shape: %.3f ms/step' % ptb['ms_per_step'])
+        del ptr, pb
 
     # ---- roofline legs: the same work once more with the library's per-kernel HIP events on (events
     # are recorded on the launch stream inside the library: cvae_profile_enable / cvae_profile_read).
@@ -299,16 +384,22 @@ def main():
         return prof
 
     log(rank, 'roofline legs')
-    prof_t = leg(lambda: [tr.train_step(batches[i]) for i in range(min(3, n_batches))])
+    n_leg = min(3, n_batches)
+    prof_t = leg(lambda: [tr.train_step(batches[i]) for i in range(n_leg)])
+    if rank == 0:
+        live = rnn_live_flops(hp, batches[:n_leg])
+        for k in ('rnn_fwd_persist_kernel', 'rnn_bwd_persist_kernel'):
+            if prof_t[k]['launches']:
+                prof_t[k]['work'] = live               # live (row, step) pairs, not the launches' padded T x R
     prof_e = None if args.no_iw else leg(lambda: tr.iw_eval(ebatches[1:], args.iw_samples))
     if rank == 0:
-        roof_train = roofline_of(prof_t, 'train step (3 steps)')
+        roof_train = roofline_of(prof_t, 'train step (%d steps)' % n_leg)
         roof_all['train'] = table(prof_t)
         roof = roof_train
         if prof_e is not None:
             roof_eval = roofline_of(prof_e, 'IW-NLL evaluation (%d batches)' % args.iw_batches)
             roof_all['iw_nll'] = table(prof_e)
-            t_train = sum(v['ms'] for v in prof_t.values()) / 3.0 * (args.steps + args.warmup)
+            t_train = sum(v['ms'] for v in prof_t.values()) / n_leg * (args.steps + args.warmup)
             t_eval = sum(v['ms'] for v in prof_e.values()) * (args.iw_batches + 1.0) / args.iw_batches
             roof = roof_eval if (roof_eval and t_eval >= t_train) else roof_train
     barrier_sync(world)
@@ -320,11 +411,11 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s-shape Coupled-VAE (vae-couple, %s): V=%d E=%d H=%d Z=%d, batch %d per GPU, '
-                                   'lengths lognormal(%.1f,%.2f) cap %d, rows of a batch ordered by length; train step + IW-NLL K=%d'
+                                   'lengths lognormal(%.1f,%.2f) cap %d, rows in corpus (shuffled) order; train step + IW-NLL K=%d'
                                    % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
                                       shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
                        'parallelism': 'dp%d' % world},
-            'iw_nll': iw, 'train_bucketed': bucketed, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
+            'iw_nll': iw, 'ptb_lstm': ptb, 'train_bucketed': bucketed, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
         }
         if world == 1 and not args.no_cpu_baseline:
             log(rank, 'CPU baseline (oracle)')

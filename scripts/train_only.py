@@ -12,7 +12,7 @@ hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], 
 tr = harness.Trainer(hp, dev, seed=0)
 B = 32
 corpus = data.Corpus(data.synthetic_sentences(B * 8, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
-sort_rows = os.environ.get('SORT_ROWS', '1') == '1'
+sort_rows = os.environ.get('SORT_ROWS', '0') == '1'
 batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=sort_rows) for i in range(8)]
 for i in range(5):
     tr.train_step(batches[i % 8])
