@@ -477,6 +477,30 @@ class _TextBase(nn.Module):
         z = _noise.normal((go.shape[0], self.latent_dim), go.device, 'prior_z')
         return self.decode_from(z, go)
 
+    def gen_interps(self, bareA, sent_lenA, bareB, sent_lenB, go, n_interps):
+        """CV/Modules/vae_couple.py:583-633 (vae.py:230-278): decode n_interps + 2 points on the segment between the
+        posterior means of A and B.  -> per sentence a list of n_interps + 2 decoded sentences (reference format)."""
+        with torch.no_grad():
+            zA, _ = self.PosteriorGaussian.params(self.Encoder.last_flat(bareA, sent_lenA), need_sigma=False)
+            _noise.normal((1,) + tuple(zA.shape), zA.device, 'eps')            # Gaussian.forward always draws
+            zB, _ = self.PosteriorGaussian.params(self.Encoder.last_flat(bareB, sent_lenB), need_sigma=False)
+            _noise.normal((1,) + tuple(zB.shape), zB.device, 'eps')
+        interps = [[] for _ in range(go.shape[0])]
+        for i in range(n_interps + 2):
+            zk = zA * ((n_interps - i + 1) / (n_interps + 1)) + zB * (i / (n_interps + 1))
+            for b, sent in enumerate(self.decode_from(zk, go)):
+                interps[b].append(sent)
+        return interps
+
+    def sample_from_posterior(self, bare, sent_len, n_sample):
+        """CV/Modules/vae_couple.py:657-679: n_sample draws of q(z|x) -> (B, n_sample, Z).  (Normal.sample draws
+        one (n_sample, B, Z) block after the (1, B, Z) draw of Gaussian.forward.)"""
+        with torch.no_grad():
+            mu, sigma = self.PosteriorGaussian.params(self.Encoder.last_flat(bare, sent_len))
+            _noise.normal((1,) + tuple(mu.shape), mu.device, 'eps')
+            eps = _noise.normal((n_sample,) + tuple(mu.shape), mu.device, 'posterior_eps')
+            return ops.rsample_n(mu, sigma, eps).transpose(0, 1).contiguous()
+
     def estimate_mi(self, go, sent_len, bare, n_sample):
         """CV/Modules/vae_couple.py:453-502 -> (mi (B,), z (B,K,Z))."""
         with torch.no_grad():
@@ -519,18 +543,27 @@ class VAE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        ro = _train_order(sent_len)
-        if ro is None:
-            last = self.Encoder.last_flat(bare, sent_len)
-            dist, z = self.PosteriorGaussian(last)
-            return self.Decoder(None, to_init(self.Decoder.toInit, z), go), dist, z, None
-        go, bare, sent_len = ro.take(go, bare, sent_len)
+        logits, dist, z, _, _ = self._run(go, sent_len, bare, _train_order(sent_len))
+        return logits, dist, z, None
+
+    def _run(self, go, sent_len, bare, ro):
+        if ro is not None:
+            go, bare, sent_len = ro.take(go, bare, sent_len)
         with _rows_in(ro):
-            last = self.Encoder.last_flat(bare, sent_len, mask_rows=None)
+            last = self.Encoder.last_flat(bare, sent_len, mask_rows='sort' if ro is None else None)
             dist, z = self.PosteriorGaussian(last)
-            logits = self.Decoder(None, to_init(self.Decoder.toInit, z), go, _order=ro)
-        dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
-        return logits, dist, ro.back(z), None
+            init = to_init(self.Decoder.toInit, z)
+            logits = self.Decoder(None, init, go, _order=ro)
+        if ro is not None:
+            dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
+            z, init = ro.back(z), ro.back(init)
+        return logits, dist, z, init, last
+
+    def saliency(self, go, sent_len=None, bare=None):
+        """CV/Modules/vae.py:348-374: the training forward that also hands out the encoder state, for
+        Experiment.analyze_saliency's torch.autograd.grad calls (rows stay in the caller's order)."""
+        logits, dist, _, init, last = self._run(go, sent_len, bare, None)
+        return logits, dist, init, last
 
 
 class DAE(_TextBase):
@@ -564,6 +597,13 @@ class DAE(_TextBase):
             latent = self._latent(bare, sent_len, mask_rows=None)
             logits = self.Decoder(None, to_init(self.Decoder.toInit, latent), go, _order=ro)
         return logits, ro.back(latent)
+
+    def saliency(self, go, sent_len=None, bare=None):
+        """CV/Modules/dae.py saliency: (logits, init_input, last_states), rows in the caller's order."""
+        last = self.Encoder.last_flat(bare, sent_len)
+        latent = ops.linear(last, self.toLatent.weight, self.toLatent.bias, ops.ACT_NONE)
+        init = to_init(self.Decoder.toInit, latent)
+        return self.Decoder(None, init, go), init, last
 
     def test_lm(self, go, sent_len, bare, eos, n_sample):
         """dae.py test_lm: one deterministic decode; nll = kl = +inf by the reference's definition."""
@@ -664,7 +704,10 @@ class VAE_COUPLE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        ro = _train_order(sent_len)
+        logits, dist, z, logits_c, init, init_c, _ = self._run(go, sent_len, bare, _train_order(sent_len))
+        return logits, dist, z, None, logits_c, init, init_c
+
+    def _run(self, go, sent_len, bare, ro):
         if ro is not None:
             go, bare, sent_len = ro.take(go, bare, sent_len)
         with _rows_in(ro):
@@ -679,7 +722,13 @@ class VAE_COUPLE(_TextBase):
         if ro is not None:
             dist = torch.distributions.Normal(ro.back(dist.loc), ro.back(dist.scale), validate_args=False)
             z, init, init_c = ro.back(z), ro.back(init), ro.back(init_c)
-        return logits, dist, z, None, logits_c, init, init_c
+        return logits, dist, z, logits_c, init, init_c, last
+
+    def saliency(self, go, sent_len=None, bare=None):
+        """CV/Modules/vae_couple.py:743-778: the training forward that also hands out the encoder state (B, 2H),
+        for Experiment.analyze_saliency's torch.autograd.grad calls (rows stay in the caller's order)."""
+        logits, dist, _, logits_c, init, init_c, last = self._run(go, sent_len, bare, None)
+        return logits, logits_c, dist, init, init_c, last
 
 
 # --------------------------------------------------------------------------- dialogue models

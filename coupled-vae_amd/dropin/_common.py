@@ -18,11 +18,20 @@ def extend_path(path_list, tree, *sub):
             path_list.append(cand)
 
 
+_synced = None
+
+
 def sync_settings():
+    """Mirror config.use_lstm into cvae_amd.settings -- once per process: Config() has directory side effects
+    (SURVEY fact 4), so the shims share one instantiation instead of one each (the reference's own modules
+    instantiate it at import too)."""
+    global _synced
     from cvae_amd.settings import settings
-    try:
-        from config import Config          # the reference's config.py, if the caller has one
-        settings.use_lstm = bool(Config().use_lstm)
-    except ImportError:
-        pass
+    if _synced is None:
+        try:
+            from config import Config          # the reference's config.py, if the caller has one
+            settings.use_lstm = bool(Config().use_lstm)
+            _synced = True
+        except ImportError:
+            _synced = False
     return settings

@@ -99,3 +99,25 @@ def test_epoch_batches_plain_and_bucketed():
     plain = np.mean([L[b].max() for b in data.epoch_batches(L, 32, seed=5)])
     buck = np.mean([L[b].max() for b in data.epoch_batches(L, 32, seed=5, bucket=True)])
     assert buck < 0.6 * plain
+
+
+def test_run_reference_launcher_puts_the_dropin_first(tmp_path):
+    """scripts/run_reference.py: an unchanged script of a reference tree must resolve `Modules.*` to the drop-in
+    classes (Python would otherwise put the script's own directory first), run as __main__ inside the tree, and
+    see its own arguments."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = tmp_path / 'Coupled-VAE'
+    tree.mkdir()
+    (tree / 'probe.py').write_text(textwrap.dedent('''
+        import os, sys
+        from Modules.Losses.SeqLoss import SeqLoss
+        from Modules.vae_couple import VAE_COUPLE
+        print(SeqLoss.__module__, VAE_COUPLE.__module__, os.path.basename(os.getcwd()), sys.argv[1:], __name__)
+    '''))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'run_reference.py'), str(tree), 'probe.py', 'x'],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout.split() == ['cvae_amd.modules', 'cvae_amd.modules', 'Coupled-VAE', "['x']", '__main__']

@@ -73,3 +73,113 @@ def test_sample_sharded_iw_nll_two_ranks():
         assert torch.equal(s0, s1), cell                                   # identical on every rank
         rel = float((s0 - one0).abs().max() / one0.abs().max())
         assert rel < 1e-5, (cell, rel)                                     # == single-process estimate
+
+
+# ----------------------------------------------------------------------------- data-parallel TRAINING step
+def _train_worker(rank, world, port, q):
+    os.environ['CVAE_PERSISTENT_RNN'] = '0'       # two processes share one GPU here: the whole-sequence kernels of
+    for p in (ROOT, os.path.join(ROOT, 'coupled-vae_amd'), os.path.join(ROOT, 'tests')):   # both cannot be co-resident
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cvae_amd import _lib, data, harness, modules
+        dev = torch.device('cuda:0')
+        _lib.init(0)
+        V, E, H, Z, Bl = _DP_SHAPE
+        out = {}
+        for cell in ('gru', 'lstm'):
+            hp = harness.HParams(model='vae-couple', cell=cell, V=V, E=E, H=H, Z=Z, dropout=0.0)
+            tr = harness.Trainer(hp, dev, seed=11)                  # identical initial weights on both ranks
+            assert tr.world == 2
+            sents = data.synthetic_sentences(world * Bl, V, 2.6, 0.5, 40, seed=12)
+            c = data.Corpus(sents)
+            batch = harness.text_batch(c, range(rank * Bl, (rank + 1) * Bl), dev)      # this rank's sentences
+            eps = torch.randn(world * Bl, Z, generator=torch.Generator().manual_seed(13))
+            mine = eps[rank * Bl:(rank + 1) * Bl].unsqueeze(0)
+            tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1
+            modules.set_noise_source(modules.ReplayNoise({'eps': [mine], 'eps_couple': [mine]}))
+            try:
+                res = tr.forward_backward(batch)                    # includes the all-reduce (mean) of the arena
+            finally:
+                modules.set_noise_source(None)
+            sd = tr.model.state_dict(keep_vars=True)
+            grads = {k: v.grad.detach().cpu().numpy().copy() for k, v in sd.items() if v.grad is not None}   # numpy: pickled by value
+            tr.opt.step()
+            torch.cuda.synchronize()
+            post = {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+            out[cell] = (float(res['tot'].detach()), grads, post)
+        assert _lib.query('cvae_persist_status') == 0
+        q.put((rank, out))
+    except Exception as e:
+        import traceback
+        q.put((rank, 'ERROR: %s\n%s' % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+_DP_SHAPE = (500, 32, 64, 8, 8)       # V, E, H, Z, sentences per rank
+
+
+def test_data_parallel_train_step_two_ranks():
+    """The product's DP training step (harness.Trainer with world size 2: per-rank forward + backward, mean
+    all-reduce of the flat gradient arena BEFORE the clip, then clip + Adam): the all-reduced gradient equals the
+    oracle's gradient of the FULL 16-sentence batch, both ranks end the step with bit-identical weights, and those
+    equal the oracle's clip + Adam on the full-batch gradient (CV/Experiment.py:509-522 clips the full batch)."""
+    from oracle import cvae_oracle as O
+    from cvae_amd import data, harness
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=200) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert not isinstance(res[r], str), res[r]
+    V, E, H, Z, Bl = _DP_SHAPE
+    sents = data.synthetic_sentences(2 * Bl, V, 2.6, 0.5, 40, seed=12)
+    eps = torch.randn(2 * Bl, Z, generator=torch.Generator().manual_seed(13))
+    bare, go, eos, ln = (torch.from_numpy(x) for x in O.make_batch([s.tolist() for s in sents], 200, truncate=True))
+    full = dict(bare=bare, go=go, eos=eos, len=ln)
+    for cell in ('gru', 'lstm'):
+        hp = harness.HParams(model='vae-couple', cell=cell, V=V, E=E, H=H, Z=Z, dropout=0.0)
+        model = harness.build_model(hp, 'cpu', seed=11)             # the workers' initial weights
+        P = O.tie_aliases({k: v.detach().clone() for k, v in model.state_dict().items()})
+        keys = list(model.state_dict().keys())
+        for p_ in {id(v): v for v in P.values()}.values():
+            p_.requires_grad_(True)
+        cfg = dict(latent_dim=Z, lambda_kl=0.37, lambda_couple=hp.lambda_couple, lambda_seq_couple=1.0,
+                   euclidean_dist=False)
+        out = O.train_forward(P, 'vae-couple', cell, full, {'eps': eps}, cfg)
+        out['tot'].backward()
+        tot0, g0, post0 = res[0][cell]
+        tot1, g1, post1 = res[1][cell]
+        g0, g1, post0, post1 = ({k: torch.from_numpy(v) for k, v in d.items()} for d in (g0, g1, post0, post1))
+        # the mean of the two ranks' totals is the full-batch total (every term is a batch mean)
+        assert abs(0.5 * (tot0 + tot1) - float(out['tot'])) < 1e-4 * abs(float(out['tot']))
+        for k in keys:
+            if P[k].grad is None:
+                continue
+            ref = P[k].grad
+            err = float((g0[k] - ref).abs().max() / (ref.abs().max() + 1e-30))
+            assert err < 1e-3, (cell, k, err)
+            assert torch.equal(g0[k], g1[k]), (cell, k)             # the same reduced gradient on both ranks
+        for k in keys:
+            assert torch.equal(post0[k], post1[k]), (cell, k)       # bit-identical weights after the step
+        grads = {k: P[k].grad.detach() for k in keys if P[k].grad is not None}
+        with torch.no_grad():
+            Q = O.tie_aliases({k: v.detach().clone() for k, v in P.items()})
+            O.clip_and_adam(Q, grads, {}, [k for k in keys if k in grads])
+        for k in keys:
+            if k in grads:
+                # Adam's first step is lr * g / (|g| + eps): where |g| is at the fp32 noise floor the step is noise
+                # too, so the 2e-4 bar is for elements with a resolved gradient; the rest moves by at most lr
+                diff = (post0[k] - Q[k]).abs()
+                solid = P[k].grad.abs() > 1e-3 * P[k].grad.abs().max()
+                assert float(diff[solid].max() / (Q[k].abs().max() + 1e-30)) < 2e-4, (cell, k)
+                assert float(diff.max()) <= 2.001e-3, (cell, k)

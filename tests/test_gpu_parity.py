@@ -556,3 +556,68 @@ def test_train_step_with_vocab_not_multiple_of_four(dev):
     with torch.no_grad():
         out = O.train_forward(P, 'vae-couple', 'lstm', cb, {'eps': eps[0]}, cfg)
     assert close(res['tot'], out['tot'], LOSS_TOL)
+
+
+def test_analysis_methods_vs_oracle(dev):
+    """gen_interps / sample_from_posterior / saliency of the mirror (CV/Modules/vae_couple.py:583-633, 657-679,
+    743-778) against the oracle's building blocks.  No fixture was recorded from the reference for these three
+    (parity unpinned against the reference itself; the blocks they are made of are pinned one by one)."""
+    from cvae_amd import modules, data, harness
+    V, E, H, Z, B, T = 300, 24, 16, 8, 6, 9
+    hp = harness.HParams(model='vae-couple', cell='gru', V=V, E=E, H=H, Z=Z, max_len=T, dropout=0.0)
+    tr = harness.Trainer(hp, dev, seed=2)
+    m = tr.model
+    P = O.tie_aliases({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    cA = data.Corpus(data.synthetic_sentences(B, V, 1.8, 0.4, 12, seed=1))
+    cB = data.Corpus(data.synthetic_sentences(B, V, 1.8, 0.4, 12, seed=2))
+    bA, bB = harness.text_batch(cA, range(B), dev), harness.text_batch(cB, range(B), dev)
+    go = torch.full((B, 1), 1, dtype=torch.int64, device=dev)
+    # ---- gen_interps: n + 2 greedy decodes of the interpolated posterior means, ids bit-exact
+    m.train(False)
+    n = 3
+    got = m.gen_interps(bA['bare'], bA['len'], bB['bare'], bB['len'], go, n)
+    assert len(got) == B and len(got[0]) == n + 2 and len(got[0][0]) == T
+    with torch.no_grad():
+        zA = O.gaussian(P, 'PosteriorGaussian.', O.encoder(P, 'Encoder.', 'gru', bA['bare'].cpu(), bA['len'].cpu()))[0]
+        zB = O.gaussian(P, 'PosteriorGaussian.', O.encoder(P, 'Encoder.', 'gru', bB['bare'].cpu(), bB['len'].cpu()))[0]
+        for i in range(n + 2):
+            zk = zA * ((n - i + 1) / (n + 1)) + zB * (i / (n + 1))
+            ref = O.decoder_greedy(P, 'Decoder.', 'gru', O.to_init(P, 'toInit.', zk), go[:, 0].cpu(), T)
+            ids = torch.tensor([[int(t) for t in got[b][i]] for b in range(B)])
+            assert torch.equal(ids, ref), i
+        # ---- sample_from_posterior: mu + sigma * eps on the recorded draw, (B, n_sample, Z)
+        eps = torch.randn(5, B, Z, generator=torch.Generator().manual_seed(3))
+        modules.set_noise_source(modules.ReplayNoise({'posterior_eps': [eps]}))
+        try:
+            smp = m.sample_from_posterior(bA['bare'], bA['len'], 5)
+        finally:
+            modules.set_noise_source(None)
+        sA = O.gaussian(P, 'PosteriorGaussian.', O.encoder(P, 'Encoder.', 'gru', bA['bare'].cpu(), bA['len'].cpu()))[1]
+        assert tuple(smp.shape) == (B, 5, Z) and rel(smp, (zA + sA * eps.double()).transpose(0, 1)) < 1e-5
+    # ---- saliency: d seq_loss / d last_states through torch.autograd.grad with retain_graph, twice
+    m.train(True)
+    eps1 = torch.randn(1, B, Z, generator=torch.Generator().manual_seed(4))
+    modules.set_noise_source(modules.ReplayNoise({'eps': [eps1]}))
+    try:
+        logits, logits_c, dist, init, init_c, last = m.saliency(go=bA['go'], sent_len=bA['len'], bare=bA['bare'])
+    finally:
+        modules.set_noise_source(None)
+    seq = m.criterionSeq(logits, bA['eos'], keep_batch=True).sum(0)
+    seq_c = m.criterionSeq(logits_c, bA['eos'], keep_batch=True).sum(0)
+    g1 = torch.autograd.grad(seq, last, retain_graph=True)[0]
+    g2 = torch.autograd.grad(seq + seq_c, last, retain_graph=True)[0]
+    g1b = torch.autograd.grad(seq, last, retain_graph=True)[0]
+    assert rel(g1b, g1) < 1e-6
+    Pg = O.tie_aliases({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    last64 = O.encoder(Pg, 'Encoder.', 'gru', bA['bare'].cpu(), bA['len'].cpu()).detach().requires_grad_(True)
+    mu, sg = O.gaussian(Pg, 'PosteriorGaussian.', last64)[:2]
+    z = mu + sg * eps1[0].double()
+    fin = O.decoder_final(Pg, 'Decoder.', 'gru', O.to_init(Pg, 'toInit.', z), bA['go'].cpu())
+    mu_c = O.gaussian(Pg, 'PosteriorGaussianCouple.', last64)[0]
+    fin_c = O.decoder_final(Pg, 'DecoderCouple.', 'gru', O.to_init(Pg, 'toInitCouple.', mu_c), bA['go'].cpu())
+    s_ref = O.seq_xent(Pg, 'Decoder.', fin, bA['eos'].cpu()).sum()
+    sc_ref = O.seq_xent(Pg, 'DecoderCouple.', fin_c, bA['eos'].cpu()).sum()
+    r1 = torch.autograd.grad(s_ref, last64, retain_graph=True)[0]
+    r2 = torch.autograd.grad(s_ref + sc_ref, last64)[0]
+    assert close(seq, s_ref, LOSS_TOL) and rel(last, last64) < 1e-5
+    assert rel(g1, r1) < GRAD_TOL and rel(g2, r2) < GRAD_TOL
