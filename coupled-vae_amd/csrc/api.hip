@@ -916,6 +916,8 @@ int cvae_projce_forward_train(const float* final, const float* W, const float* b
   return projce_forward_impl(final, W, b, tgt, pad, nseg, T, R, E, V, loss_row, lse, sent, ws, logits, stream);
 }
 
+int cvae_projce_bf16x3(int on) { return ce_set_bf16x3(on); }
+
 int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {
   if (ce_fast_supported((int)E)) return ce_fast_bwd_workspace_floats(N, (int)V);
   return projce_bwd_workspace_floats((int)N, (int)V) + N;   // + broadcast of gsent over time

@@ -329,6 +329,224 @@ __global__ __launch_bounds__(256, 2) void ce_core_kernel(CeArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same core with the product on the bf16 matrix pipe, error-compensated ("bf16x3"): every fp32 operand is
+// split into hi = bf16(v) and lo = bf16(v - hi), and  x.w  is accumulated in fp32 as  hi.hi + hi.lo + lo.hi
+// (v_mfma_f32_32x32x16_bf16: 16x the rate of the fp32-input MFMA, so 3 passes cost 3/16 of it).  The dropped
+// lo.lo term and the 16-bit truncation of hi + lo leave a relative error of ~2^-16 per product; for a logit (a sum
+// of E = 200 products of magnitude ~0.03) that is an absolute error of a few 1e-6, measured against fp64 in
+// tests/test_gpu_kernels.py::test_projce_bf16x3_error (the fp32-input kernel above: ~1e-7; the bars: 1e-4 / 1e-3).
+// W is split ONCE per launch into the tile-blocked image the LDS wants (ce_presplit_kernel: per 32-row tile a
+// [32][LDR] block of hi then one of lo, LDR = 16*NB + 8 bf16 -> row stride an odd number of 16-byte units: the
+// b128 fragment reads are conflict-free), so staging is a straight 16-byte copy; a row's K values are split in
+// registers when the item starts.  Everything else -- live-row list, persistent items, vocabulary split, S^T
+// formulation, online softmax, SAVE / GRAD epilogues -- is the fp32 kernel's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void bf3_split(f32x8 v, bf16x8& hi, bf16x8& lo) {
+  hi = __builtin_convertvector(v, bf16x8);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void ce_presplit_kernel(int V, int E, const float* __restrict__ W, int vec,
+                                                          bf16x8* __restrict__ Wp) {
+  constexpr int LDR8 = 2 * NB + 1;                       // bf16x8 units per LDS row
+  const int ntiles = (V + CE_TN - 1) / CE_TN;
+  const long total = (long)ntiles * CE_TN * LDR8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int u = (int)(i % LDR8), row = (int)((i / LDR8) % CE_TN), tile = (int)(i / ((long)LDR8 * CE_TN));
+    const int v = tile * CE_TN + row, k = 8 * u;
+    f32x8 x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    if (v < V && k < E) {
+      const float* src = W + (long)v * E + k;
+      if (vec && k + 7 < E) {
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k + j < E) x[j] = src[j];
+      }
+    }
+    bf16x8 hi, lo;
+    bf3_split(x, hi, lo);
+    bf16x8* t = Wp + (long)tile * 2 * CE_TN * LDR8;
+    t[row * LDR8 + u] = hi;
+    t[CE_TN * LDR8 + row * LDR8 + u] = lo;
+  }
+}
+
+template <int NB, bool GRAD, bool SAVE>
+__global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf16x8* __restrict__ Wp) {
+  constexpr int LDR8 = 2 * NB + 1;
+  constexpr int TILE8 = 2 * CE_TN * LDR8;        // bf16x8 units per tile (hi block + lo block)
+  constexpr int NST = (TILE8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16x8 Wt[2][TILE8];
+  __shared__ float Bt[2][CE_TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int nlive = *p.nlive;
+  int rbeg = 0, rend = nlive;
+  if (GRAD) {
+    rbeg = p.r0;
+    rend = min(nlive, p.r0 + p.rcount);
+  }
+  if (rend <= rbeg) return;
+  const int rb = (rend - rbeg + CE_ROWS - 1) / CE_ROWS;
+  const int ntiles = (p.V + CE_TN - 1) / CE_TN;
+  const int nsplit = ce_pick_split(rb, ntiles, p.cap, gridDim.x);
+  const int tps = (ntiles + nsplit - 1) / nsplit;
+
+  bf16x8 st[NST];
+  float bst = 0.f;
+  auto stage_load = [&](int tile) {
+    const bf16x8* src = Wp + (long)tile * TILE8;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + 256 * i;
+      if (NST * 256 == TILE8 || idx < TILE8) st[i] = src[idx];
+    }
+    const int n0 = tile * CE_TN;
+    if (tid < CE_TN) bst = (n0 + tid < p.V) ? p.bias[n0 + tid] : -INFINITY;
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + 256 * i;
+      if (NST * 256 == TILE8 || idx < TILE8) Wt[buf][idx] = st[i];
+    }
+    if (tid < CE_TN) Bt[buf][tid] = bst;
+  };
+
+  for (int item = blockIdx.x; item < rb * nsplit; item += gridDim.x) {
+    const int sp = item % nsplit, rbi = item / nsplit;
+    const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
+    const int ci = rbeg + rbi * CE_ROWS + wave * 32 + l31;     // index into the live list
+    const bool rv = ci < rend;
+    const int n = rv ? p.rows[ci] : 0;
+    // this lane's row as B fragments of the 32x32x16 MFMA: block Q uses k = 16Q + 8*lhi + (0..7)
+    bf16x8 xh[NB], xl[NB];
+    {
+      const float* xr = p.X + (long)n * p.E + 8 * lhi;
+#pragma unroll
+      for (int Q = 0; Q < NB; ++Q) {
+        f32x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (rv && 16 * Q + 8 * lhi < p.E) {       // E % 8 == 0 and 16-byte rows (host-checked): whole groups of 8
+          const float4 a = *reinterpret_cast<const float4*>(xr + 16 * Q), b = *reinterpret_cast<const float4*>(xr + 16 * Q + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        bf3_split(v, xh[Q], xl[Q]);
+      }
+    }
+    int tg = -1;
+    if (rv) {
+      const int64_t t = p.tgt[n % p.TR];
+      if (t >= 0 && t < p.V) tg = (int)t;
+    }
+    float m = -INFINITY, s = 0.f, tlv = 0.f;
+    bool found = false;
+    float lse_r = 0.f, coef = 0.f;
+    float* prow = nullptr;
+    if (GRAD) {
+      if (rv) {
+        lse_r = p.lse[n];
+        coef = p.gsent[(n / p.TR) * p.R + n % p.R];
+      }
+      prow = p.P + (long)(ci - p.r0) * p.ldp;
+    }
+    if (SAVE) prow = p.P + (long)ci * p.ldp;
+
+    stage_load(t0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const int buf = (t - t0) & 1;
+      const int n0 = t * CE_TN;
+#ifndef CE_EXP_NOLOAD
+      if (t + 1 < t1) stage_load(t + 1);
+#endif
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const bf16x8* wh = &Wt[buf][l31 * LDR8 + lhi];
+      const bf16x8* wl = wh + CE_TN * LDR8;
+#pragma unroll
+      for (int Q = 0; Q < NB; ++Q) {
+        const bf16x8 ah = wh[2 * Q], al = wl[2 * Q];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[Q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[Q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[Q], acc, 0, 0, 0);
+      }
+      // acc[r] = logit(row = this lane's, vocab column n0 + j), j = (r & 3) + 8 * (r >> 2) + 4 * lhi
+      float xv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        xv[r] = acc[r] + Bt[buf][j];     // -inf beyond V
+      }
+#ifdef CE_EXP_NOEPI
+      if (!GRAD && !SAVE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += xv[r];
+      } else
+#endif
+      if (!GRAD) {
+        float mx = xv[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, xv[r]);
+        const float mn = fmaxf(m, mx);
+        const float mref = (mn == -INFINITY) ? 0.f : mn;
+        float sum = s * __expf(m - mref);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __expf(xv[r] - mref);
+        s = sum;
+        m = mn;
+        const int jt = tg - n0 - 4 * lhi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (jt == (r & 3) + 8 * (r >> 2)) { tlv = xv[r]; found = true; }
+        if (SAVE && rv) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(prow + n0 + 8 * g + 4 * lhi) =
+                make_float4(xv[4 * g], xv[4 * g + 1], xv[4 * g + 2], xv[4 * g + 3]);
+        }
+      } else {
+        const int jt = tg - n0 - 4 * lhi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            o[i] = coef * (__expf(xv[r] - lse_r) - ((jt == i + 8 * g) ? 1.f : 0.f));
+          }
+          if (rv) *reinterpret_cast<float4*>(prow + n0 + 8 * g + 4 * lhi) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      if (t + 1 < t1) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+    if (!GRAD) {
+      const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
+      lse_merge2(m, s, m2, s2);
+      if (rv) {
+        if (lhi == 0) {
+          p.pm[(long)sp * p.pstride + ci] = m;
+          p.ps[(long)sp * p.pstride + ci] = s;
+        }
+        if (found) p.tl[ci] = tlv;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, float* __restrict__ loss,
                                                           float* __restrict__ lse) {
   const int nlive = *p.nlive;
@@ -384,10 +602,35 @@ static int ce_cap(long N, int V) {
 
 bool ce_fast_supported(int E) { return E >= 1 && E <= 200; }
 
+// bf16x3 path: 16-byte rows, E a multiple of 8 (every shipped config: E = 200); CVAE_CE_BF16X3=0 selects the
+// fp32-input MFMA kernel instead (diagnostics, error measurements)
+static int bf3_blocks(int E) {                   // 16-wide K blocks, rounded up to an instantiated count
+  const int nb = (E + 15) / 16;
+  return nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 7 ? 7 : 13;
+}
+static int g_bf3_on = -1;                        // -1: not set yet (env CVAE_CE_BF16X3, default on)
+static bool bf3_enabled() {
+  if (g_bf3_on < 0) { const char* e = getenv("CVAE_CE_BF16X3"); g_bf3_on = (e && e[0] == '0') ? 0 : 1; }
+  return g_bf3_on != 0;
+}
+int ce_set_bf16x3(int on) {                      // returns the previous setting
+  const int prev = bf3_enabled() ? 1 : 0;
+  g_bf3_on = on ? 1 : 0;
+  return prev;
+}
+static bool bf3_ok(const CeArgs& a) { return bf3_enabled() && a.vec && a.E % 8 == 0 && a.E <= 208; }
+// floats of workspace for the split image of W (16-byte aligned start included)
+static long bf3_presplit_floats(int E, int V) {
+  const long ntiles = cdiv(V, CE_TN);
+  return ntiles * 2 * CE_TN * (2 * bf3_blocks(E) + 1) * 4 + 8;
+}
+
+
 // workspace (floats): rows[N] | counts | nlive | tl[N] | pm[cap*N] | ps[cap*N]
 static long ce_counts_slots(long N) { return (N + 1023) / 1024 + 8; }
+static long ce_fwd_base_floats(long N, int V) { return N + ce_counts_slots(N) + N + 2L * ce_cap(N, V) * N + 16; }
 long ce_fast_workspace_floats(long N, int V) {
-  return N + ce_counts_slots(N) + N + 2L * ce_cap(N, V) * N + 16;
+  return ce_fwd_base_floats(N, V) + bf3_presplit_floats(208, V);       // + the split image of W (bf16x3 path)
 }
 
 static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* rows, int* counts, int* nlive,
@@ -401,8 +644,29 @@ static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* ro
 }
 
 template <bool GRAD, bool SAVE = false>
-static int launch_core(const CeArgs& a, hipStream_t s) {
+static int launch_core(const CeArgs& a, hipStream_t s, float* presplit_ws = nullptr) {
   const dim3 grid(persistent_grid_blocks()), block(256);
+  if (presplit_ws && bf3_ok(a)) {
+    bf16x8* Wp = reinterpret_cast<bf16x8*>((reinterpret_cast<uintptr_t>(presplit_ws) + 15) & ~(uintptr_t)15);
+    const int nb = bf3_blocks(a.E);
+    const long units = (long)cdiv(a.V, CE_TN) * CE_TN * (2 * nb + 1);
+    int pg = (int)((units + 255) / 256);
+    if (pg > 4096) pg = 4096;
+#define CE_BF3(NB_)                                                                                        \
+    do {                                                                                                   \
+      hipLaunchKernelGGL((ce_presplit_kernel<NB_>), dim3(pg), dim3(256), 0, s, a.V, a.E, a.W, a.vec, Wp);  \
+      CVAE_LAUNCH_CHECK("ce_presplit_kernel");                                                             \
+      hipLaunchKernelGGL((ce_core_bf3_kernel<NB_, GRAD, SAVE>), grid, block, 0, s, a, Wp);                 \
+    } while (0)
+    if (nb == 1) CE_BF3(1);
+    else if (nb == 2) CE_BF3(2);
+    else if (nb == 4) CE_BF3(4);
+    else if (nb == 7) CE_BF3(7);
+    else CE_BF3(13);
+#undef CE_BF3
+    CVAE_LAUNCH_CHECK("ce_core_bf3_kernel");
+    return 0;
+  }
   const int nq = (a.E + 7) / 8;
 #define CE_CASE(NQ_)                                                                          \
   do {                                                                                        \
@@ -457,9 +721,9 @@ int launch_ce_fast_forward(const float* X, const float* W, const float* bias, co
     if (logits) {
       CVAE_REQUIRE(aligned16(logits), "ce_forward: logits buffer must be 16-byte aligned");
       a.P = logits; a.ldp = ce_ldp(V);
-      CVAE_TRY((launch_core<false, true>(a, s)));
+      CVAE_TRY((launch_core<false, true>(a, s, ws + ce_fwd_base_floats(N, V))));
     } else {
-      CVAE_TRY(launch_core<false>(a, s));
+      CVAE_TRY(launch_core<false>(a, s, ws + ce_fwd_base_floats(N, V)));
     }
   }
   hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a, persistent_grid_blocks(), loss, lse);
@@ -481,9 +745,10 @@ static long ce_chunk_rows(long N, int V) {
   return ch < nr ? ch : nr;
 }
 // workspace (floats): rows[N] | counts | nlive | P[chunk * ldp] | split-K slabs
-long ce_fast_bwd_workspace_floats(long N, int V) {
+static long ce_bwd_base_floats(long N, int V) {
   return N + ce_counts_slots(N) + 16 + ce_chunk_rows(N, V) * ce_ldp(V) + gemm_wide_part_floats(200, true) + 16;
 }
+long ce_fast_bwd_workspace_floats(long N, int V) { return ce_bwd_base_floats(N, V) + bf3_presplit_floats(208, V); }
 
 // dX [N,E] overwritten; dW [V,E], db [V] overwritten.
 int launch_ce_fast_backward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
@@ -532,7 +797,7 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
       CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
     } else {
       ProfScope prof(PK_CE_FWD, s, 2.0 * lrc * E * V);
-      CVAE_TRY(launch_core<true>(a, s));
+      CVAE_TRY(launch_core<true>(a, s, ws + ce_bwd_base_floats(N, V)));
     }
     G224Args gx = {};      // dX[rows[r0+m], :] += P[m, :] . W
     gx.A = P; gx.lda = ldp; gx.B = W; gx.ldb = E; gx.C = dX; gx.ldc = E;
