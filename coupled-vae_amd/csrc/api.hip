@@ -50,6 +50,17 @@ static bool prof_event(hipEvent_t* e) {
 
 bool prof_enabled() { return g_prof_on; }
 
+static int g_split_bf16 = -1;                    // -1: not set yet (env CVAE_SPLIT_BF16, default on)
+bool split_bf16_enabled() {
+  if (g_split_bf16 < 0) { const char* e = getenv("CVAE_SPLIT_BF16"); g_split_bf16 = (e && e[0] == '0') ? 0 : 1; }
+  return g_split_bf16 != 0;
+}
+int split_bf16_set(int on) {
+  const int prev = split_bf16_enabled() ? 1 : 0;
+  g_split_bf16 = on ? 1 : 0;
+  return prev;
+}
+
 ProfScope::ProfScope(int kernel, hipStream_t stream, double work) : slot(-1), s(stream) {
   if (!g_prof_on || g_prof.size() >= kProfMaxRecs) return;
   ProfRec r;
@@ -916,7 +927,7 @@ int cvae_projce_forward_train(const float* final, const float* W, const float* b
   return projce_forward_impl(final, W, b, tgt, pad, nseg, T, R, E, V, loss_row, lse, sent, ws, logits, stream);
 }
 
-int cvae_projce_bf16x3(int on) { return ce_set_bf16x3(on); }
+int cvae_split_bf16(int on) { return split_bf16_set(on); }
 
 int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {
   if (ce_fast_supported((int)E)) return ce_fast_bwd_workspace_floats(N, (int)V);

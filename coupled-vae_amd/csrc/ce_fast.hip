@@ -602,23 +602,13 @@ static int ce_cap(long N, int V) {
 
 bool ce_fast_supported(int E) { return E >= 1 && E <= 200; }
 
-// bf16x3 path: 16-byte rows, E a multiple of 8 (every shipped config: E = 200); CVAE_CE_BF16X3=0 selects the
-// fp32-input MFMA kernel instead (diagnostics, error measurements)
+// bf16x3 path: 16-byte rows, E a multiple of 8 (every shipped config: E = 200); cvae_split_bf16(0) / CVAE_SPLIT_BF16=0
+// selects the fp32-input MFMA kernel instead (diagnostics, error measurements)
 static int bf3_blocks(int E) {                   // 16-wide K blocks, rounded up to an instantiated count
   const int nb = (E + 15) / 16;
   return nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 7 ? 7 : 13;
 }
-static int g_bf3_on = -1;                        // -1: not set yet (env CVAE_CE_BF16X3, default on)
-static bool bf3_enabled() {
-  if (g_bf3_on < 0) { const char* e = getenv("CVAE_CE_BF16X3"); g_bf3_on = (e && e[0] == '0') ? 0 : 1; }
-  return g_bf3_on != 0;
-}
-int ce_set_bf16x3(int on) {                      // returns the previous setting
-  const int prev = bf3_enabled() ? 1 : 0;
-  g_bf3_on = on ? 1 : 0;
-  return prev;
-}
-static bool bf3_ok(const CeArgs& a) { return bf3_enabled() && a.vec && a.E % 8 == 0 && a.E <= 208; }
+static bool bf3_ok(const CeArgs& a) { return split_bf16_enabled() && a.vec && a.E % 8 == 0 && a.E <= 208; }
 // floats of workspace for the split image of W (16-byte aligned start included)
 static long bf3_presplit_floats(int E, int V) {
   const long ntiles = cdiv(V, CE_TN);

@@ -44,6 +44,11 @@ struct ProfScope {
 
 bool prof_enabled();   // true while cvae_profile_enable(1) is in effect
 
+// Error-compensated split-bf16 products ("bf16x3", ce_fast.hip / rnn_large.hip): on by default, env CVAE_SPLIT_BF16=0
+// or cvae_split_bf16(0) selects the fp32-input MFMA kernels instead.
+bool split_bf16_enabled();
+int split_bf16_set(int on);      // returns the previous setting
+
 // ---- library-owned device scratch (api.hip): one buffer per (kind, device, stream), so launches on different
 // streams (or host threads driving different streams) never share flag words, exchange slabs or index lists.
 // Allocated at first use and regrown only when a larger shape arrives (warm-up; hipFree of the old buffer

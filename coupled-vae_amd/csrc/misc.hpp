@@ -90,7 +90,6 @@ int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStre
 
 // ce_fast.hip (E <= 200): live-row compaction + register-resident rows + 224-wide split-K GEMMs
 bool ce_fast_supported(int E);
-int ce_set_bf16x3(int on);
 long ce_fast_workspace_floats(long N, int V);
 int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
                            long N, long TR, int E, int V, float* loss, float* lse, float* ws, float* logits,

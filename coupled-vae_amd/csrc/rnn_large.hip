@@ -187,6 +187,185 @@ __global__ __launch_bounds__(256, RL_OCC_) void rnn_large_step_kernel(RnnLargeAr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same step with the gate product on the bf16 matrix pipe, error-compensated ("bf16x3", see ce_fast.hip):
+// h and W_hh are split into hi + lo bf16 while they are staged (registers -> LDS), and each 16-deep K block costs
+// three v_mfma_f32_32x32x16_bf16 per gate (hi.lo, lo.hi, hi.hi) instead of eight v_mfma_f32_32x32x2_f32 at twice the
+// cycles each.  Tile and roles as above (128 rows x 32 units x G gates, a wave's N-tile j is gate j: the cell stays
+// lane-local); K chunk 32 (two MFMA K blocks per barrier); LDS rows are 32 bf16 = four 16-byte slots, slot index
+// XOR-swizzled with (row >> 2) & 3 so that the b128 fragment reads of 16 consecutive rows are conflict-free
+// without padding: 2 x (A hi|lo + B hi|lo) = 64 KB, two blocks per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+constexpr int RB_BK = 32;
+
+__device__ __forceinline__ void rb_split(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+  f32x8 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  hi = __builtin_convertvector(v, bf16x8);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+
+template <int CELL>
+__global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs p) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  constexpr int BROWS = G * RL_BU;                      // rows of the B tile: gate-major, 32 units each
+  // LDS image, in bf16x8 (16-byte) slots: [buf][A hi: 128 rows x 4][A lo][B hi: BROWS x 4][B lo]
+  constexpr int A_SL = RL_BM * 4, B_SL = BROWS * 4, BUF_SL = 2 * A_SL + 2 * B_SL;
+  extern __shared__ __attribute__((aligned(16))) float rl_smem[];
+  bf16x8* sm = reinterpret_cast<bf16x8*>(rl_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int H = p.H, GH = G * H;
+  const int nu = H / RL_BU, L = blockIdx.x;
+  const int rowtile = ((L >> 3) / nu) * 8 + (L & 7), utile = (L >> 3) % nu;
+  const int u0 = utile * RL_BU, m0 = rowtile * RL_BM;
+  if (m0 >= p.live) return;
+
+  // staging tasks: one task = 8 consecutive k of one row = one LDS slot.  A: 512 tasks, B: BROWS * 4 (384 / 512)
+  constexpr int NTA = 2, NTB = (B_SL + 255) / 256;
+  constexpr bool NB_EXACT = NTB * 256 == B_SL;
+  const float* __restrict__ gA = p.h_prev;
+  const float* __restrict__ gB = p.W_hh;
+  long oa[NTA], ob[NTB];
+  int sa_slot[NTA], sb_slot[NTB];
+#pragma unroll
+  for (int i = 0; i < NTA; ++i) {
+    const int idx = tid + 256 * i, r = idx >> 2, sl = idx & 3;
+    oa[i] = (long)min(m0 + r, p.live - 1) * H + 8 * sl;
+    sa_slot[i] = r * 4 + (sl ^ ((r >> 2) & 3));
+  }
+#pragma unroll
+  for (int i = 0; i < NTB; ++i) {
+    const int idx = min(tid + 256 * i, B_SL - 1), r = idx >> 2, sl = idx & 3;      // r: gate r / 32, unit r % 32
+    ob[i] = (long)((r >> 5) * H + u0 + (r & 31)) * H + 8 * sl;
+    sb_slot[i] = r * 4 + (sl ^ ((r >> 2) & 3));
+  }
+  int kload = 0;
+  f32x4 ra[NTA][2], rb[NTB][2];
+#define RB_STAGE_LOAD()                                                                          \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i) {                                            \
+      ra[i][0] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload);                            \
+      ra[i][1] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload + 4);                        \
+    }                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NTB; ++i) {                                            \
+      rb[i][0] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload);                            \
+      rb[i][1] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload + 4);                        \
+    }                                                                                            \
+    kload += RB_BK;                                                                              \
+  } while (0)
+#define RB_STAGE_STORE(buf)                                                                      \
+  do {                                                                                           \
+    bf16x8* base = sm + (buf) * BUF_SL;                                                          \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i) {                                            \
+      bf16x8 hi, lo;                                                                             \
+      rb_split(ra[i][0], ra[i][1], hi, lo);                                                      \
+      base[sa_slot[i]] = hi;                                                                     \
+      base[A_SL + sa_slot[i]] = lo;                                                              \
+    }                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NTB; ++i) {                                            \
+      if (NB_EXACT || tid + 256 * i < B_SL) {                                                    \
+        bf16x8 hi, lo;                                                                           \
+        rb_split(rb[i][0], rb[i][1], hi, lo);                                                    \
+        base[2 * A_SL + sb_slot[i]] = hi;                                                        \
+        base[2 * A_SL + B_SL + sb_slot[i]] = lo;                                                 \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  // fragment slots of this lane: A row wave*32 + l31, B row g*32 + l31 (same swizzle term for all: (l31 >> 2) & 3)
+  const int arow = wave * 32 + l31, sw = (l31 >> 2) & 3;
+  const int nk = H / RB_BK;
+  RB_STAGE_LOAD();
+  RB_STAGE_STORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) RB_STAGE_LOAD();
+    const bf16x8* base = sm + buf * BUF_SL;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int sl = (2 * kb + lhi) ^ sw;
+      const bf16x8 ah = base[arow * 4 + sl], al = base[A_SL + arow * 4 + sl];
+      bf16x8 bh[G], bl[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bh[g] = base[2 * A_SL + (g * RL_BU + l31) * 4 + sl];
+        bl[g] = base[2 * A_SL + B_SL + (g * RL_BU + l31) * 4 + sl];
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
+    }
+    if (kt + 1 < nk) RB_STAGE_STORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef RB_STAGE_LOAD
+#undef RB_STAGE_STORE
+
+  // cell: identical to rnn_large_step_kernel (lane = unit u0 + l31; acc[g][r] = gate g of row
+  // m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lhi)
+  const int u = u0 + l31;
+  float bh_[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bh_[g] = p.b_hh[g * H + u];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    float x[4][G], hp[4], cp[4];
+    int mm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wave * 32 + j + 8 * rg + 4 * lhi;
+      mm[j] = m;
+      const int mc = min(m, p.live - 1);
+      const float* xp = p.xproj + (long)((mc / p.xdiv) % p.xmod) * GH + u;
+#pragma unroll
+      for (int g = 0; g < G; ++g) x[j][g] = xp[g * H];
+      if (p.xadd) {
+        const float* xa = p.xadd + (long)mc * GH + u;
+#pragma unroll
+        for (int g = 0; g < G; ++g) x[j][g] += xa[g * H];
+      }
+      hp[j] = p.h_prev[(long)mc * H + u];
+      cp[j] = (CELL == CELL_LSTM) ? p.c_prev[(long)mc * H + u] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * rg + j;
+      float sg[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) sg[g] = acc[g][r] + bh_[g];
+      const long o = (long)mm[j] * H + u;
+      if constexpr (CELL == CELL_GRU) {
+        const float rgate = sigmoidf_(x[j][0] + sg[0]);
+        const float zg = sigmoidf_(x[j][1] + sg[1]);
+        const float nn = tanhf_(x[j][2] + rgate * sg[2]);
+        if (mm[j] < p.live) p.h_out[o] = (1.f - zg) * nn + zg * hp[j];
+      } else {
+        const float ig = sigmoidf_(x[j][0] + sg[0]);
+        const float fg = sigmoidf_(x[j][1] + sg[1]);
+        const float gg = tanhf_(x[j][2] + sg[2]);
+        const float og = sigmoidf_(x[j][3] + sg[3]);
+        const float cnew = fg * cp[j] + ig * gg;
+        if (mm[j] < p.live) {
+          p.h_out[o] = og * tanhf_(cnew);
+          p.c_out[o] = cnew;
+        }
+      }
+    }
+  }
+}
+
 bool rnn_large_fused_supported(int cell, int H, const float* h, const float* W_hh) {
   static int on = -1;
   if (on < 0) {
@@ -217,6 +396,21 @@ int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const 
     attr_set = true;
   }
   ProfScope prof(PK_RNN_LARGE, s, 2.0 * live * G * H * (double)H);
+  if (split_bf16_enabled() && H % RB_BK == 0) {
+    const size_t lds3 = (size_t)2 * (2 * RL_BM * 4 + 2 * G * RL_BU * 4) * 16;      // 64 KB (LSTM) / 56 KB (GRU)
+    static bool attr3 = false;
+    if (!attr3) {
+      CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_large_step_bf3_kernel<CELL_GRU>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "rnn_large bf3 LDS attribute"));
+      CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_large_step_bf3_kernel<CELL_LSTM>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "rnn_large bf3 LDS attribute"));
+      attr3 = true;
+    }
+    if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_large_step_bf3_kernel<CELL_GRU>, grid, block, lds3, s, a);
+    else hipLaunchKernelGGL(rnn_large_step_bf3_kernel<CELL_LSTM>, grid, block, lds3, s, a);
+    CVAE_LAUNCH_CHECK("rnn_large_step_bf3_kernel");
+    return 0;
+  }
   if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_large_step_kernel<CELL_GRU>, grid, block, lds, s, a);
   else hipLaunchKernelGGL(rnn_large_step_kernel<CELL_LSTM>, grid, block, lds, s, a);
   CVAE_LAUNCH_CHECK("rnn_large_step_kernel");

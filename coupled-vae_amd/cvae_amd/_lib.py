@@ -56,7 +56,7 @@ SIGNATURES = {
     'cvae_persist_status_peek': [],
     'cvae_persist_status_set': [I],
     'cvae_projce_workspace': [L, L, L],
-    'cvae_projce_bf16x3': [I],
+    'cvae_split_bf16': [I],
     'cvae_projce_forward': [P, P, P, P, L, I, I, I, I, L, P, P, P, P, P],
     'cvae_projce_backward_workspace': [L, L, L],
     'cvae_projce_backward': [P, P, P, P, L, P, P, I, I, I, I, L, P, P, P, P, P],

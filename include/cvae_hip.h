@@ -197,12 +197,7 @@ int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64
  * -> loss_row[nseg*T*R] (0 where tgt == pad), lse[nseg*T*R], sent[nseg*R] = sum over t.
  * ws: cvae_projce_workspace(nseg*T*R, E, V) floats. */
 int64_t cvae_projce_workspace(int64_t N, int64_t E, int64_t V);
-/* Arithmetic of the hidden x vocab product inside cvae_projce_* (E <= 200, E % 8 == 0, 16-byte rows).  1 (default):
- * error-compensated split-bf16 ("bf16x3": every fp32 operand = hi + lo in bf16, product = hi.hi + hi.lo + lo.hi on
- * v_mfma_f32_32x32x16_bf16, fp32 accumulation; relative error ~2^-16 per product; measured against fp64 at E = 200, V = 20000: per-sentence loss 2.0e-7 relative
- * against 1.7e-7 for the fp32-input MFMA kernel, gradients 9.8e-7 for both: tests/test_gpu_kernels.py::test_projce_bf16x3_error).  0: fp32-input MFMA
- * (v_mfma_f32_32x32x2_f32), 5x slower.  Returns the previous setting; env CVAE_CE_BF16X3=0 sets the default. */
-int cvae_projce_bf16x3(int on);
+
 int cvae_projce_forward(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
                         int nseg, int T, int R, int E, int64_t V, float* loss_row, float* lse, float* sent,
                         float* ws, void* stream);
@@ -304,6 +299,16 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
                    int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
                    float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
                    void* stream);
+
+/* ---- arithmetic of the large dense products (no reference counterpart: torch computes them in fp32).  The
+ * hidden x vocab product of cvae_projce_* (E <= 200, E % 8 == 0, 16-byte rows) and the many-row recurrent gate
+ * product of the IW-evaluation decoder (R > 256) run as error-compensated split-bf16 ("bf16x3") by default: every
+ * fp32 operand = hi + lo in bf16, product = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation -- relative error ~2^-16 per product.  Measured against fp64 at E = 200, V = 20000: per-sentence loss
+ * 2.0e-7 relative (fp32-input MFMA kernel: 1.7e-7), gradients 9.8e-7 for both
+ * (tests/test_gpu_kernels.py::test_projce_bf16x3_error).  cvae_split_bf16(0) selects the fp32-input MFMA kernels
+ * (v_mfma_f32_32x32x2_f32, ~5x slower); returns the previous setting; env CVAE_SPLIT_BF16=0 sets the default. */
+int cvae_split_bf16(int on);
 
 /* ---- measurement aid, no reference counterpart: opt-in HIP-event timing of the library's
  * own kernels on the launch stream (bench.py's roofline leg).  enable(1) resets and starts

@@ -540,16 +540,16 @@ def test_projce_bf16x3_error(dev):
     ref = O.seq_xent(P, 'D.', f64, eos)
     (ref * gs.double()).sum().backward()
     errs = {}
-    prev = _lib.query('cvae_projce_bf16x3', 1)
+    prev = _lib.query('cvae_split_bf16', 1)
     try:
         for mode in (1, 0):
-            _lib.query('cvae_projce_bf16x3', mode)
+            _lib.query('cvae_split_bf16', mode)
             fd = final.to(dev).requires_grad_(True)
             got = ops.proj_ce(fd, W.to(dev), b.to(dev), eos.to(dev), 0)
             (got * gs.to(dev)).sum().backward()
             errs[mode] = (float((got.double().cpu() - ref).abs().max()), rel(got, ref), rel(fd.grad, f64.grad))
     finally:
-        _lib.query('cvae_projce_bf16x3', prev)
+        _lib.query('cvae_split_bf16', prev)
     print('CE product error vs fp64 (sentence-sum abs, sentence-sum rel, grad rel): bf16x3 %s | fp32 MFMA %s' % (errs[1], errs[0]))
     assert errs[1][1] < 2e-6 and errs[1][2] < 1e-4
     assert errs[1][1] < 20 * max(errs[0][1], 1e-8)
