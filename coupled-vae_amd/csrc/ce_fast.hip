@@ -476,12 +476,27 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const bf16x8* wh = &Wt[buf][l31 * LDR8 + lhi];
       const bf16x8* wl = wh + CE_TN * LDR8;
+      // fragments are fetched CE_PF K blocks ahead of their MFMAs (register ring): an LDS round trip is longer
+      // than the three MFMAs of one block, and the scheduler otherwise sinks each read next to its use
+#ifndef CE_PF
+#define CE_PF 3
+#endif
+      bf16x8 fa[CE_PF + 1], fl[CE_PF + 1];
+#pragma unroll
+      for (int Q = 0; Q < CE_PF && Q < NB; ++Q) { fa[Q] = wh[2 * Q]; fl[Q] = wl[2 * Q]; }
 #pragma unroll
       for (int Q = 0; Q < NB; ++Q) {
-        const bf16x8 ah = wh[2 * Q], al = wl[2 * Q];
+        if (Q + CE_PF < NB) { fa[(Q + CE_PF) % (CE_PF + 1)] = wh[2 * (Q + CE_PF)]; fl[(Q + CE_PF) % (CE_PF + 1)] = wl[2 * (Q + CE_PF)]; }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CE_EXP_NOLDS
+        const bf16x8 ah = xh[(Q + 1) % NB], al = xl[(Q + 1) % NB];
+#else
+        const bf16x8 ah = fa[Q % (CE_PF + 1)], al = fl[Q % (CE_PF + 1)];
+#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[Q], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[Q], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[Q], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // acc[r] = logit(row = this lane's, vocab column n0 + j), j = (r & 3) + 8 * (r >> 2) + 4 * lhi
       float xv[16];
