@@ -329,6 +329,304 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same products on the bf16 matrix pipe with error compensation (see ce_fast.hip), here with THREE bf16 terms per
+// fp32 operand (hi + mid + lo = 24 significant bits, the whole fp32 value) and the six products whose weight is above
+// 2^-24 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid): "bf16x6".  These are the gradient products of the training
+// step, which feed long sums with cancellation (a decoder's d init is a sum over ~200 timesteps): with two terms
+// ("bf16x3", relative error ~2^-17 per product) the worst gradient of the reference fixtures moved from 2.4e-5 to
+// 2.5e-4 of its tensor's largest entry -- inside the 1e-3 bar but ten times the fp32 kernels' error -- while the
+// kernel is bound by its staging, not by the matrix pipe, so the three extra passes cost little.  Work layout,
+// k-ranges, live-row lists, ones column, slabs and reduction are exactly those of gemm_wide_kernel; what differs is
+// the inner machinery.  v_mfma_f32_32x32x16_bf16 wants, per lane, 8 CONSECUTIVE k of one row of A and of one column of B,
+// while B (and A in the weight-gradient products) is k-major in memory.  So the staging pass transposes: a thread
+// loads an 8(k) x 4(columns) block with eight 16-byte loads, splits every value into its bf16 terms and writes, per
+// column, the 8 k-values as one 16-byte slot of a [column][16 k] LDS image (one image per term).  A k-contiguous
+// A needs no transpose (two 16-byte loads = one slot).  Rows of the images are 32 bytes (two slots); the slot index
+// is XORed with (row >> 3) & 1, which makes the b128 fragment reads of 16 consecutive rows conflict-free.
+// Fragment j of a wave covers columns 32j .. 32j+31 (natural order: the epilogue stores one column per lane).
+// Requires 16-byte aligned operands with leading dimensions that are multiples of 4 (the launcher checks).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+#ifndef GW_DEEP_RING
+#define GW_DEEP_RING 0      // 1: two-chunk-ahead register ring (measured: spills at 2 waves per SIMD)
+#endif
+
+__device__ __forceinline__ void gw_split(const f32x8 v, bf16x8 (&t)[3]) {
+  t[0] = __builtin_convertvector(v, bf16x8);
+  const f32x8 r1 = v - __builtin_convertvector(t[0], f32x8);
+  t[1] = __builtin_convertvector(r1, bf16x8);
+  t[2] = __builtin_convertvector(r1 - __builtin_convertvector(t[1], f32x8), bf16x8);
+}
+
+template <bool AKC, int NF>
+__global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
+  constexpr int BN = NF * 32;
+  // LDS, in 16-byte slots: [buf][A hi: 128 rows x 2][A mid][A lo][B hi: BN rows x 2][B mid][B lo]
+  constexpr int A_SL = G2_BM * 2, B_SL = BN * 2, BUF_SL = 3 * A_SL + 3 * B_SL;
+  __shared__ __attribute__((aligned(16))) bf16x8 sm[2 * BUF_SL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const WideLayout L = wide_layout(p, gridDim.x);
+  const int Mlim = L.Mlim, Klim = L.Klim;
+  if (Mlim <= 0 || Klim <= 0) return;
+  const int mt = L.mt, nt = p.ntiles, ks = L.ks, kchunk = L.kchunk;
+  const int items = mt * nt * ks;
+  const int tw = p.tile_w;
+  const int nf4 = tw >> 2;                     // 4-column groups of a B tile
+  const int ones_col = p.extra ? tw : -1;
+
+  // image rows that staging never writes (columns >= tw): zero, except the ones column (1.0 = hi 1, lo 0)
+  {
+    bf16x8 zero, one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { zero[j] = (__bf16)0.f; one[j] = (__bf16)1.f; }     // 1.0 = hi 1, mid 0, lo 0
+    for (int i = tid; i < 2 * 3 * B_SL; i += 256) {
+      const int buf = i / (3 * B_SL), r = i % (3 * B_SL), img = r / B_SL, row = (r % B_SL) >> 1;
+      if (row >= tw) sm[buf * BUF_SL + 3 * A_SL + img * B_SL + (r % B_SL)] = (row == ones_col && img == 0) ? one : zero;
+    }
+  }
+  // staging roles.  A k-contiguous: every thread one (row, k-half) slot.  A k-major: threads 0..63 one
+  // (4 columns, k-half) block.  B: nb_tasks = 2 * nf4 blocks on threads tb0 .. tb0 + nb_tasks - 1.
+  const int tb0 = AKC ? 0 : 64;
+  const bool has_b = tid >= tb0 && tid < tb0 + 2 * nf4;
+  const int b_cg = has_b ? (tid - tb0) % nf4 : 0, b_kh = has_b ? (tid - tb0) / nf4 : 0;
+  const bool has_a = AKC || tid < 64;
+  const int a_row = tid >> 1, a_kh = AKC ? (tid & 1) : (tid >> 5), a_cg = tid & 31;
+  __syncthreads();
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int ntile = item % nt, mtile = (item / nt) % mt, ksp = item / (nt * mt);
+    const int m0 = mtile * G2_BM, n0 = ntile * tw;
+    const int ncols = min(tw, p.N - n0);
+    const int kbeg = ksp * kchunk, kend = min(Klim, kbeg + kchunk);
+
+    // Staging registers, two sets (chunks are fetched TWO chunks ahead of their MFMAs: a chunk of three bf16 passes
+    // is shorter than an L2 round trip).  A k-major A block and a B block never share a thread, so one 8 x float4
+    // block per set serves both roles; a k-contiguous A adds its two float4 per set.  The deep ring is dropped
+    // where the registers do not allow it (k-contiguous A with 224-wide tiles).
+    constexpr bool DEEP = (GW_DEEP_RING != 0) && !(AKC && NF == 7);
+    float4 ra_[2][AKC ? 2 : 1], rt_[2][8];
+    // one K chunk (16 k from k0) of this item into registers; out-of-range k / rows / columns read as zero
+    auto load = [&](int k0, float4 (&ra)[AKC ? 2 : 1], float4 (&rt)[8]) {
+      if (AKC) {
+        const int mm = min(m0 + a_row, Mlim - 1);
+        const long arow = p.a_ind ? (long)p.rows[p.r0 + mm] : (long)mm;
+        const int k = k0 + 8 * a_kh;
+        const float* src = p.A + arow * p.lda + k;
+        ra[0] = (k + 3 < kend) ? *reinterpret_cast<const float4*>(src) : ld4g(src, k, kend, 0);
+        ra[1] = (k + 7 < kend) ? *reinterpret_cast<const float4*>(src + 4) : ld4g(src + 4, k + 4, kend, 0);
+      } else if (has_a) {
+        const int m = m0 + 4 * a_cg;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = k0 + 8 * a_kh + kk;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k < kend && m < Mlim) {
+            const long arow = p.a_ind ? (long)p.rows[p.r0 + k] : (long)k;
+            const float* src = p.A + arow * p.lda + m;
+            v = (m + 3 < Mlim) ? *reinterpret_cast<const float4*>(src) : ld4g(src, m, Mlim, 0);
+          }
+          rt[kk] = v;
+        }
+      }
+      if (has_b) {
+        const int c = 4 * b_cg;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = k0 + 8 * b_kh + kk;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k < kend && c < ncols) {
+            const long brow = (p.dev_bound == 2) ? (long)p.rows[p.r0 + k] : (long)k;
+            const float* src = p.B + brow * p.ldb + n0 + c;
+            v = (c + 3 < ncols) ? *reinterpret_cast<const float4*>(src) : ld4g(src, c, ncols, 0);
+          }
+          rt[kk] = v;
+        }
+      }
+    };
+    auto store = [&](int buf, const float4 (&ra)[AKC ? 2 : 1], const float4 (&rt)[8]) {
+      bf16x8* base = sm + buf * BUF_SL;
+      if (AKC) {
+        f32x8 v;
+        v[0] = ra[0].x; v[1] = ra[0].y; v[2] = ra[0].z; v[3] = ra[0].w;
+        v[4] = ra[1].x; v[5] = ra[1].y; v[6] = ra[1].z; v[7] = ra[1].w;
+        bf16x8 t[3];
+        gw_split(v, t);
+        const int sl = a_row * 2 + (a_kh ^ ((a_row >> 3) & 1));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) base[q * A_SL + sl] = t[q];
+      } else if (has_a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x8 v;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) v[kk] = reinterpret_cast<const float*>(&rt[kk])[j];
+          bf16x8 t[3];
+          gw_split(v, t);
+          const int row = 4 * a_cg + j, sl = row * 2 + (a_kh ^ ((row >> 3) & 1));
+#pragma unroll
+          for (int q = 0; q < 3; ++q) base[q * A_SL + sl] = t[q];
+        }
+      }
+      if (has_b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x8 v;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) v[kk] = reinterpret_cast<const float*>(&rt[kk])[j];
+          bf16x8 t[3];
+          gw_split(v, t);
+          const int row = 4 * b_cg + j, sl = row * 2 + (b_kh ^ ((row >> 3) & 1));
+#pragma unroll
+          for (int q = 0; q < 3; ++q) base[3 * A_SL + q * B_SL + sl] = t[q];
+        }
+      }
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int arow_l = wave * 32 + l31;
+    const int a_sl = arow_l * 2 + (lhi ^ ((arow_l >> 3) & 1));
+    const int b_sw = lhi ^ ((l31 >> 3) & 1);            // rows 32j + l31: (row >> 3) & 1 == (l31 >> 3) & 1
+    auto compute = [&](int buf) {
+      const bf16x8* base = sm + buf * BUF_SL;
+      const bf16x8 ah = base[a_sl], am = base[A_SL + a_sl], al = base[2 * A_SL + a_sl];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int bs = 3 * A_SL + (32 * j + l31) * 2 + b_sw;
+        const bf16x8 bh = base[bs], bm = base[B_SL + bs], bl = base[2 * B_SL + bs];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);      // smallest terms first
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    };
+
+    // interior chunks (every load a whole in-bounds float4: full k range, full column groups, and for a k-major A
+    // a full row tile) take a branch-free path on per-task base pointers; k-major operands that go through the
+    // row list fetch their 8 row indices per chunk with two 16-byte loads
+    const bool fast_item = ncols == tw && (AKC || m0 + G2_BM <= Mlim);
+    const float* fa;
+    const float* fb = p.B + n0 + 4 * b_cg;
+    if (AKC) {
+      const int mm = min(m0 + a_row, Mlim - 1);
+      fa = p.A + (p.a_ind ? (long)p.rows[p.r0 + mm] : (long)mm) * p.lda + 8 * a_kh;
+    } else {
+      fa = p.A + m0 + 4 * a_cg;
+    }
+    const bool rows16 = ((p.r0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.rows) & 15) == 0);   // 16-byte aligned slices of 4 indices
+    auto fast_load = [&](int k0, float4 (&ra)[AKC ? 2 : 1], float4 (&rt)[8]) {
+      if (AKC) {
+        ra[0] = *reinterpret_cast<const float4*>(fa + k0);
+        ra[1] = *reinterpret_cast<const float4*>(fa + k0 + 4);
+      } else if (has_a) {
+        const int kb = k0 + 8 * a_kh;
+        if (p.a_ind) {
+          int ri[8];
+          if (rows16) {
+            const int4 q0 = *reinterpret_cast<const int4*>(p.rows + p.r0 + kb), q1 = *reinterpret_cast<const int4*>(p.rows + p.r0 + kb + 4);
+            ri[0] = q0.x; ri[1] = q0.y; ri[2] = q0.z; ri[3] = q0.w; ri[4] = q1.x; ri[5] = q1.y; ri[6] = q1.z; ri[7] = q1.w;
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) ri[kk] = p.rows[p.r0 + kb + kk];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)ri[kk] * p.lda);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)(kb + kk) * p.lda);
+        }
+      }
+      if (has_b) {
+        const int kb = k0 + 8 * b_kh;
+        if (p.dev_bound == 2) {
+          int ri[8];
+          if (rows16) {
+            const int4 q0 = *reinterpret_cast<const int4*>(p.rows + p.r0 + kb), q1 = *reinterpret_cast<const int4*>(p.rows + p.r0 + kb + 4);
+            ri[0] = q0.x; ri[1] = q0.y; ri[2] = q0.z; ri[3] = q0.w; ri[4] = q1.x; ri[5] = q1.y; ri[6] = q1.z; ri[7] = q1.w;
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) ri[kk] = p.rows[p.r0 + kb + kk];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fb + (long)ri[kk] * p.ldb);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fb + (long)(kb + kk) * p.ldb);
+        }
+      }
+    };
+    const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
+    const int nfast = fast_item ? (kend - kbeg) / G2_BK : 0;   // interior chunks form a prefix
+    auto fetch = [&](int c, float4 (&ra)[AKC ? 2 : 1], float4 (&rt)[8]) {      // chunk c of the item -> a register set
+      if (c < nfast) fast_load(kbeg + c * G2_BK, ra, rt);
+      else if (c < nk) load(kbeg + c * G2_BK, ra, rt);
+    };
+    if (DEEP) {
+      fetch(0, ra_[0], rt_[0]);
+      store(0, ra_[0], rt_[0]);
+      fetch(1, ra_[1], rt_[1]);
+      __syncthreads();
+      for (int kt = 0; kt < nk; kt += 2) {
+        // chunk kt in LDS buffer 0, chunk kt+1 in register set 1
+        fetch(kt + 2, ra_[0], rt_[0]);
+        compute(0);
+        if (kt + 1 < nk) store(1, ra_[1], rt_[1]);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // chunk kt+1 in LDS buffer 1, chunk kt+2 in register set 0
+        fetch(kt + 3, ra_[1], rt_[1]);
+        compute(1);
+        if (kt + 2 < nk) store(0, ra_[0], rt_[0]);
+        __syncthreads();
+      }
+    } else {
+      fetch(0, ra_[0], rt_[0]);
+      store(0, ra_[0], rt_[0]);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        fetch(kt + 1, ra_[0], rt_[0]);
+        compute(kt & 1);
+        if (kt + 1 < nk) store((kt & 1) ^ 1, ra_[0], rt_[0]);
+        __syncthreads();
+      }
+    }
+
+    // epilogue: acc[j][r] -> row m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lhi, column 32j + l31 of the tile
+    const bool direct = (ks == 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row >= Mlim) continue;
+      float* c;
+      if (direct) {
+        const long crow = (p.dev_bound == 1) ? (long)p.rows[p.r0 + row] : (long)row;
+        c = p.C + crow * p.ldc + n0;
+      } else {
+        c = p.part + ((long)(ksp * mt + mtile) * G2_BM + (row - m0)) * p.part_ld + n0;
+      }
+      const bool acc_c = direct && p.beta;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int cj = 32 * j + l31;
+        const float v = acc[j][r];
+        if (cj < ncols) c[cj] = v + (acc_c ? c[cj] : 0.f);
+        else if (cj == ones_col && ntile == 0) {
+          if (direct) p.extra[row] = v + (p.beta ? p.extra[row] : 0.f);
+          else c[p.N] = v;
+        }
+      }
+    }
+  }
+}
+
 // C (+)= sum over the ks slabs, in slab order (deterministic).  One thread per (row, 4 columns).
 __global__ __launch_bounds__(256) void gemm_wide_reduce_kernel(G224Args p, int nblk) {
   const WideLayout L = wide_layout(p, nblk);
@@ -413,7 +711,15 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
     if (a.dev_bound == 1 && a.prof_units > 0) pm = (double)a.prof_units;
     if (a.dev_bound == 2 && a.prof_units > 0) pk = (double)a.prof_units;
     ProfScope prof(PK_GEMM_WIDE, s, 2.0 * pm * a.N * pk);
-    if (akc) {
+    if (split_bf16_enabled() && a.vecA && a.vecB) {
+      if (akc) {
+        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 7>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 4>), grid, block, 0, s, a);
+      } else {
+        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 7>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 4>), grid, block, 0, s, a);
+      }
+    } else if (akc) {
       if (wide) hipLaunchKernelGGL((gemm_wide_kernel<true, 7>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, block, 0, s, a);
     } else {
