@@ -35,9 +35,10 @@ import torch.distributed as dist   # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, dense fp32-input matrix (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # dense bf16 (16x the fp32-input rate: v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
-# kernels whose product runs as error-compensated split-bf16 (three bf16 MFMA passes per fp32 product): their
-# algorithmic fp32 FLOP/s are priced against the bf16 peak / 3
-SPLIT_BF16_KERNELS = ('ce_core_kernel', 'rnn_large_step_kernel')
+# kernels whose product runs as error-compensated split-bf16: operands split into two bf16 terms and three bf16
+# MFMA passes per fp32 product (bf16x3: forward products), or three terms and six passes (bf16x6: the gradient
+# products of gemm_wide).  Their algorithmic fp32 FLOP/s are priced against the bf16 peak / passes
+SPLIT_BF16_KERNELS = {'ce_core_kernel': 3, 'rnn_large_step_kernel': 3, 'gemm_wide_kernel': 6}
 SPLIT_BF16 = True
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
            3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
@@ -106,7 +107,8 @@ def pmc_traffic(kernel):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             rec = json.load(open(path))['ce_core_forward_eval_launch']
-            if 'false, true, false' not in rec.get('kernel', 'false, true, false'):
+            # the record must be of the variant this run launches (split-bf16 or fp32-input)
+            if ('ce_core_bf3_kernel' in rec.get('kernel', '')) != SPLIT_BF16:
                 continue
             return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
         except (OSError, KeyError, ValueError, TypeError):
@@ -124,7 +126,10 @@ def roofline_of(prof, region):
     if rec['bound'] == 'mfma':
         ach, peak, unit = per_s / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
         if SPLIT_BF16 and name in SPLIT_BF16_KERNELS:
-            peak, arith = round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1), 'bf16x3 (hi.hi + hi.lo + lo.hi, fp32 accumulation)'
+            passes = SPLIT_BF16_KERNELS[name]
+            peak = round(PEAK_BF16_MFMA_TFLOPS / passes, 1)
+            arith = ('bf16x3 (hi.hi + hi.lo + lo.hi, fp32 accumulation)' if passes == 3 else
+                     'bf16x6 (three-term split, the six leading products, fp32 accumulation)')
     else:
         ach, peak, unit = per_s / 1e9, PEAK_HBM_GBS, 'GB/s'
     out = dict(kernel=name, region=region, bound=rec['bound'], achieved=round(ach, 3), peak=peak, unit=unit,
@@ -132,9 +137,9 @@ def roofline_of(prof, region):
                avg_launch_ms=round(rec['ms'] / rec['launches'], 5),
                work_per_launch=rec['work'] / rec['launches'], arithmetic=arith)
     if arith != 'f32':
-        out['note'] = ('achieved = algorithmic fp32 FLOP/s (2*rows*E*V per launch); peak = dense bf16 MFMA peak / 3 passes; '
+        out['note'] = ('achieved = algorithmic fp32 FLOP/s (2*M*N*K per launch); peak = dense bf16 MFMA peak / %d passes; '
                        'against the fp32-input MFMA peak of %.1f TFLOP/s the same figure is %.2fx'
-                       % (PEAK_F32_MFMA_TFLOPS, ach / PEAK_F32_MFMA_TFLOPS))
+                       % (SPLIT_BF16_KERNELS[name], PEAK_F32_MFMA_TFLOPS, ach / PEAK_F32_MFMA_TFLOPS))
     return out
 
 
@@ -430,7 +435,8 @@ def main():
             'dtype': 'f32',
             'dtype_note': ('fp32 storage, accumulation and results; the hidden x vocab product and the many-row gate product of '
                            'IW evaluation run as error-compensated split-bf16 (3 bf16 MFMA passes per fp32 product; error vs fp64 '
-                           'equal to the fp32-input MFMA kernels: tests/test_gpu_kernels.py::test_projce_bf16x3_error)'
+                           'equal to the fp32-input MFMA kernels: tests/test_gpu_kernels.py::test_projce_bf16x3_error), the '
+                           'sequence-wide gradient products with a three-term split (6 passes; scripts/grad_error_modes.py)'
                            if SPLIT_BF16 else 'fp32-input MFMA everywhere (CVAE_SPLIT_BF16=0)'), 'data': 'synthetic',
             'config': {'workload': '%s-shape Coupled-VAE (vae-couple, %s): V=%d E=%d H=%d Z=%d, batch %d per GPU, '
                                    'lengths lognormal(%.1f,%.2f) cap %d, rows in corpus (shuffled) order; train step + IW-NLL K=%d'

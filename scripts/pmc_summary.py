@@ -4,7 +4,7 @@ usage: python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_count
 
 rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 bytes) per dispatch; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes and is doubled here, as
 MI355X_MICROARCH.md prescribes.  The record `ce_core_forward_eval_launch` averages the large
-IW-evaluation launches of ce_core_kernel<NQ, GRAD=false, EXACT, SAVE=false> (those above half the largest one): it is the
+IW-evaluation launches of the CE core kernel (GRAD=false, SAVE=false; those above half the largest one): it is the
 `roofline.traffic` figure bench.py reports for its dominant kernel."""
 import collections
 import csv
@@ -31,12 +31,14 @@ def main():
     rec = None
 
     def is_eval_ce(name):
-        # ce_core_kernel<NQ, GRAD, EXACT, SAVE>: the evaluation launches are GRAD = false AND SAVE = false (the
-        # training forward is <.., false, .., true>: it also stores the live rows' logits)
-        if 'ce_core_kernel<' not in name:
-            return False
-        targs = [t.strip() for t in name.split('ce_core_kernel<')[1].split('>')[0].split(',')]
-        return len(targs) == 4 and targs[1] == 'false' and targs[3] == 'false'
+        # ce_core_bf3_kernel<NB, GRAD, SAVE> (split-bf16, the default) or ce_core_kernel<NQ, GRAD, EXACT, SAVE>
+        # (CVAE_SPLIT_BF16=0): the evaluation launches are GRAD = false AND SAVE = false (the training forward
+        # is <.., SAVE = true>: it also stores the live rows' logits)
+        for stem, n in (('ce_core_bf3_kernel<', 3), ('ce_core_kernel<', 4)):
+            if stem in name:
+                targs = [t.strip() for t in name.split(stem)[1].split('>')[0].split(',')]
+                return len(targs) == n and targs[1] == 'false' and targs[-1] == 'false'
+        return False
 
     key = [k for k in fa if is_eval_ce(k)]
     key.sort(key=lambda k: -max(fa[k]))
