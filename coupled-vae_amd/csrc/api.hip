@@ -928,6 +928,7 @@ int cvae_projce_forward_train(const float* final, const float* W, const float* b
 }
 
 int cvae_split_bf16(int on) { return split_bf16_set(on); }
+int64_t cvae_stream_rnn_min_bytes(int64_t bytes) { return stream_rnn_min_weight_bytes(bytes); }
 
 int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {
   if (ce_fast_supported((int)E)) return ce_fast_bwd_workspace_floats(N, (int)V);

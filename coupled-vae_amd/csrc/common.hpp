@@ -53,7 +53,8 @@ int split_bf16_set(int on);      // returns the previous setting
 // streams (or host threads driving different streams) never share flag words, exchange slabs or index lists.
 // Allocated at first use and regrown only when a larger shape arrives (warm-up; hipFree of the old buffer
 // synchronises the device); steady-state calls allocate nothing.  Guarded by a mutex.
-enum LibScratchKind { LS_PERSIST_SYNC = 0, LS_PERSIST_EXCH = 1, LS_WIDE_PART = 2, LS_ROWS = 3, LS_KINDS = 4 };
+enum LibScratchKind { LS_PERSIST_SYNC = 0, LS_PERSIST_EXCH = 1, LS_WIDE_PART = 2, LS_ROWS = 3, LS_STREAM_IMG = 4,
+                      LS_STREAM_PARTS = 5, LS_KINDS = 6 };
 // zero != 0: a new buffer is zero-filled (synchronously) before it is handed out.  fresh (optional): set when
 // this call (re)allocated.
 int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero = 0, bool* fresh = nullptr);
@@ -186,6 +187,22 @@ int launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 // lock-step timesteps of independent recurrences (two encoder directions, two decoders).
 constexpr int SKINNY_MAX_BATCH = 4;
 int launch_skinny_multi(const SkinnyArgs* a, int n, int epi, hipStream_t s);
+
+// Weight-streaming variant of the few-row product (skinny.hip), for recurrent weights far larger than the chip's
+// L2 (the scale-up shape: W_hh of a 2048-unit LSTM is 67 MB): error-compensated split-bf16 (bf16x3) on
+// v_mfma_f32_16x16x32_bf16, the weights read from a fragment-ordered bf16 hi / lo image that
+// launch_stream_presplit writes once per sequence, M <= 64 rows, K % 32 == 0.
+//   EPI_GRU / EPI_LSTM: one block = 16 hidden units x all gates over the whole K, fused cell epilogue (as skinny).
+//   EPI_LINEAR        : one block = 64 output columns x one of `ksplit` K ranges; writes the partial products
+//                       parts[(q*ksplit + y)*M*N + m*N + n] (problem q, K range y): the caller sums them.
+bool stream_rnn_supported(int R, int H, int G);        // shape + switch (split-bf16 on, weights >= the threshold)
+long stream_rnn_min_weight_bytes(long set_to);         // < 0: query; returns the previous threshold
+size_t stream_image_bytes(int ncols, int K);
+// column (block bx, group g, j) of the image = row `bx*cb + g*gs + j` of op(B); element (col, k) = W[col*col_stride + k*k_stride]
+int launch_stream_presplit(const float* W, long col_stride, long k_stride, int ncols, int K, int ng, int cb, long gs,
+                           void* img, hipStream_t s);
+int launch_skinny_stream(const SkinnyArgs* a, void* const* imgs, int n, int epi, int ksplit, float* parts, hipStream_t s);
+int stream_linear_ksplit(int n, int N, int K);
 
 
 // One direction of a 1-layer GRU/LSTM over T steps (rnn.hip).  State slots: hs/cs hold T+1

@@ -375,7 +375,9 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
   }
   // Long-K products with a k-major B and at most a few hundred columns (weight gradients over
   // T*B rows, input gradients): persistent split-K kernel of gemm_wide.hip.
-  if (!d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= 1024 && d.M >= 64) {
+  // (wider outputs too when the split-bf16 kernel runs them: the 2048-column weight gradients of the scale-up shape)
+  const int wide_max_n = split_bf16_enabled() ? 4096 : 1024;
+  if (!d.transB && d.act == ACT_NONE && !d.bias && d.K >= 512 && d.N <= wide_max_n && d.M >= 64) {
     G224Args w = {};
     w.A = d.A; w.lda = d.lda; w.B = d.B; w.ldb = d.ldb; w.C = d.C; w.ldc = d.ldc;
     w.M = d.M; w.N = d.N; w.K = d.K; w.beta = d.beta;

@@ -694,6 +694,18 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   const int n_eff = a.N + (a.extra ? 1 : 0);
   bool wide;
   wide_tiling(a.N, a.extra != nullptr, &wide, &a.ntiles, &a.tile_w);
+  if (!a.extra) {
+    // more tiles than resident blocks (one k-range per tile): the launch runs in rounds, so pick the tile width
+    // by rounds x columns per tile (8192 x 2048 outputs: 640 tiles of 224 = 2 rounds of 7, 1024 tiles of 128 = 2 of 4)
+    const long mt = cdiv(a.M, G2_BM), nb = wide_grid_blocks();
+    const long nt7 = cdiv(a.N, 224), nt4 = cdiv(a.N, 128);
+    if (mt * nt7 > nb || mt * nt4 > nb) {
+      const double c7 = (double)cdiv(mt * nt7, nb) * 7.0, c4 = (double)cdiv(mt * nt4, nb) * 4.0 * 1.08;
+      wide = c7 <= c4;
+      a.ntiles = (int)(wide ? nt7 : nt4);
+      a.tile_w = cdiv(cdiv(a.N, a.ntiles), 4) * 4;
+    }
+  }
   a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
   a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
   a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
@@ -703,8 +715,10 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
     if (!mc) { const char* e = getenv("CVAE_WIDE_MIN_CHUNKS"); mc = e ? atoi(e) : 4; if (mc < 1 || mc > 256) mc = 4; }
     a.min_chunks = mc;
   }
-  if (!a.part) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part, s));
   const int nblk = wide_grid_blocks();
+  // slabs are only touched when the device picks more than one k-range per tile (same test as the reduction below)
+  const bool may_split = (long)cdiv(a.M, G2_BM) * a.ntiles * 2 <= nblk || a.dev_bound;
+  if (!a.part && may_split) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part, s));
   const dim3 grid(nblk), block(256);
   {
     double pm = a.M, pk = a.K;
@@ -729,7 +743,7 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   }
   CVAE_LAUNCH_CHECK("gemm_wide_kernel");
   // the reduction is a no-op (early exit) when the device picked one k-range per tile
-  if ((long)cdiv(a.M, G2_BM) * a.ntiles * 2 <= nblk || a.dev_bound) {
+  if (may_split) {
     const long total = (long)a.M * (a.part_ld / 4);
     int rb = (int)((total + 255) / 256);
     if (rb > 2048) rb = 2048;

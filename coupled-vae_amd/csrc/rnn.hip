@@ -141,6 +141,26 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
   return 0;
 }
 
+// Weights far beyond L2 (stream_rnn_supported): one launch per step of the weight-streaming split-bf16 kernel,
+// W_hh of every sequence pre-split once into its fragment-ordered bf16 hi / lo image (library scratch).
+static int rnn_forward_stream(const RnnFwd* a, int ns, hipStream_t s) {
+  const int G = a[0].cell == CELL_GRU ? 3 : 4, H = a[0].H;
+  const size_t img_bytes = stream_image_bytes(G * H, H);
+  void* base = nullptr;
+  CVAE_TRY(lib_scratch(LS_STREAM_IMG, s, ns * img_bytes, &base));
+  void* imgs[SKINNY_MAX_BATCH];
+  for (int q = 0; q < ns; ++q) {
+    imgs[q] = static_cast<char*>(base) + q * img_bytes;
+    CVAE_TRY(launch_stream_presplit(a[q].W_hh, H, 1, G * H, H, G, 16, H, imgs[q], s));
+  }
+  SkinnyArgs k[SKINNY_MAX_BATCH];
+  for (int i = 0; i < a[0].T; ++i) {
+    for (int q = 0; q < ns; ++q) rnn_forward_step_args(a[q], i, k[q]);
+    CVAE_TRY(launch_skinny_stream(k, imgs, ns, a[0].cell == CELL_GRU ? EPI_GRU : EPI_LSTM, 1, nullptr, s));
+  }
+  return 0;
+}
+
 int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
   CVAE_REQUIRE(ns >= 1 && ns <= SKINNY_MAX_BATCH, "rnn_forward: %d sequences (max %d)", ns, SKINNY_MAX_BATCH);
   ZeroBatch zb(s);
@@ -162,6 +182,7 @@ int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
   if (aligned && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns))
     return launch_rnn_forward_persist(a, ns, s, &zb);      // its flag words join the same zero launch
   CVAE_TRY(zb.flush());
+  if (aligned && stream_rnn_supported(a[0].R, a[0].H, a[0].cell == CELL_GRU ? 3 : 4)) return rnn_forward_stream(a, ns, s);
   SkinnyArgs k[SKINNY_MAX_BATCH];
   for (int i = 0; i < a[0].T; ++i) {
     for (int q = 0; q < ns; ++q) rnn_forward_step_args(a[q], i, k[q]);
@@ -242,6 +263,110 @@ static int rnn_backward_check(const RnnBwd& a) {
 
 static int rnn_backward_large(const RnnBwd& a, hipStream_t s);
 
+// cell backward of one step for up to four lock-stepped sequences (blockIdx.y); the incoming gradient is
+// dh + the K-range partial products of the previous launch (parts[q][p][R*H], p < nparts) + dhs_t.
+// gates == nullptr: only folds the partial products into dh (the gradient wrt the initial state).
+struct CellBwdSeq {
+  const float *dhs_t, *gates, *h_prev, *c_prev, *c_cur;
+  float *dgx, *dgh, *dh, *dc;
+  const int64_t* lengths;
+  int t;
+};
+struct CellBwdBatch { CellBwdSeq q[SKINNY_MAX_BATCH]; };
+
+template <int CELL>
+__global__ __launch_bounds__(256) void cell_bwd_parts_kernel(CellBwdBatch b, int R, int H, const float* __restrict__ parts,
+                                                             int nparts) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  const CellBwdSeq& q = b.q[blockIdx.y];
+  const long RH = (long)R * H;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= RH) return;
+  const int r = (int)(idx / H), n = (int)(idx % H);
+  float dh = q.dh[idx];
+  if (parts) {
+    const float* pp = parts + (long)blockIdx.y * nparts * RH + idx;
+    for (int p = 0; p < nparts; ++p) dh += pp[p * RH];
+  }
+  if (!q.gates) { q.dh[idx] = dh; return; }
+  if (q.dhs_t) dh += q.dhs_t[idx];
+  const bool live = (q.lengths == nullptr) || ((int64_t)q.t < q.lengths[r]);
+  float dc = (CELL == CELL_LSTM) ? q.dc[idx] : 0.f;
+  const float direct = cell_bwd_point<CELL>(live, dh, dc, q.gates + (long)r * 4 * H + n, H, q.h_prev[idx],
+                                            CELL == CELL_LSTM ? q.c_prev[idx] : 0.f,
+                                            CELL == CELL_LSTM ? q.c_cur[idx] : 0.f, q.dgx + (long)r * G * H + n,
+                                            q.dgh ? q.dgh + (long)r * G * H + n : nullptr);
+  q.dh[idx] = direct;
+  if constexpr (CELL == CELL_LSTM) q.dc[idx] = dc;
+}
+
+// Weights far beyond L2: per step one cell-backward launch (all sequences) and one weight-streaming product
+// dG_t . W_hh split over K ranges (partial products in library scratch, summed by the next cell launch: fixed order).
+static int rnn_backward_stream(const RnnBwd* arr, int ns, hipStream_t s) {
+  const int T = arr[0].T, H = arr[0].H, R = arr[0].R, cell = arr[0].cell;
+  const int G = cell == CELL_GRU ? 3 : 4;
+  const long RH = (long)R * H;
+  for (int q = 0; q < ns; ++q) {
+    const RnnBwd& a = arr[q];
+    if (a.dh_last) CVAE_TRY(launch_copy(a.dh0, a.dh_last, RH, s));
+    else CVAE_TRY(launch_zero(a.dh0, RH, s));
+    if (cell == CELL_LSTM) {
+      if (a.dc_last) CVAE_TRY(launch_copy(a.dc0, a.dc_last, RH, s));
+      else CVAE_TRY(launch_zero(a.dc0, RH, s));
+    }
+  }
+  if (T == 0) return 0;
+  const size_t img_bytes = stream_image_bytes(H, G * H);
+  void* base = nullptr;
+  CVAE_TRY(lib_scratch(LS_STREAM_IMG, s, ns * img_bytes, &base));
+  void* imgs[SKINNY_MAX_BATCH];
+  for (int q = 0; q < ns; ++q) {
+    imgs[q] = static_cast<char*>(base) + q * img_bytes;
+    // op(B)[k = gate row][n = unit] = W_hh[k*H + n]; four adjacent 16-column tiles per block
+    CVAE_TRY(launch_stream_presplit(arr[q].W_hh, 1, H, H, G * H, 4, 64, 16, imgs[q], s));
+  }
+  const int ks = stream_linear_ksplit(ns, H, G * H);
+  void* pbuf = nullptr;
+  CVAE_TRY(lib_scratch(LS_STREAM_PARTS, s, (size_t)ns * ks * RH * sizeof(float), &pbuf));
+  float* parts = static_cast<float*>(pbuf);
+  const dim3 cgrid(cdiv(RH, 256), ns);
+  SkinnyArgs kk[SKINNY_MAX_BATCH];
+  for (int i = T - 1; i >= -1; --i) {
+    CellBwdBatch cb = {};
+    for (int q = 0; q < ns; ++q) {
+      const RnnBwd& a = arr[q];
+      CellBwdSeq& c = cb.q[q];
+      c.dh = a.dh0; c.dc = a.dc0;
+      if (i < 0) continue;                                   // last launch: fold the partial products into dh0
+      const int t = a.reverse ? T - 1 - i : i;
+      const int in_slot = a.reverse ? t + 1 : t, out_slot = a.reverse ? t : t + 1;
+      const long goff = (long)t * R * G * H;
+      c.dhs_t = a.dhs ? a.dhs + (long)t * RH : nullptr;
+      c.gates = a.gates + (long)t * R * 4 * H;
+      c.h_prev = a.hs + in_slot * RH;
+      c.c_prev = a.cs ? a.cs + in_slot * RH : nullptr;
+      c.c_cur = a.cs ? a.cs + out_slot * RH : nullptr;
+      c.dgx = a.dgx + goff; c.dgh = a.dgh ? a.dgh + goff : nullptr;
+      c.lengths = a.lengths; c.t = t;
+      SkinnyArgs& k = kk[q];
+      k = SkinnyArgs{};
+      k.A = (a.dgh ? a.dgh : a.dgx) + goff; k.lda = (long)G * H;
+      k.M = R; k.N = H; k.K = G * H; k.ngroups = 4;
+    }
+    const float* pin = (i == T - 1) ? nullptr : parts;
+    {
+      ProfScope prof(PK_CELL_BWD, s, 4.0 * RH * ns * (4 + 2 * G + 4 + ks));
+      if (cell == CELL_GRU)
+        hipLaunchKernelGGL((cell_bwd_parts_kernel<CELL_GRU>), cgrid, dim3(256), 0, s, cb, R, H, pin, ks);
+      else
+        hipLaunchKernelGGL((cell_bwd_parts_kernel<CELL_LSTM>), cgrid, dim3(256), 0, s, cb, R, H, pin, ks);
+      CVAE_LAUNCH_CHECK("cell_bwd_parts_kernel");
+    }
+    if (i >= 0) CVAE_TRY(launch_skinny_stream(kk, imgs, ns, EPI_LINEAR, ks, parts, s));
+  }
+  return 0;
+}
+
 int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
   CVAE_REQUIRE(ns >= 1 && ns <= SKINNY_MAX_BATCH, "rnn_backward: %d sequences (max %d)", ns, SKINNY_MAX_BATCH);
   for (int q = 0; q < ns; ++q) {
@@ -258,6 +383,7 @@ int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
     aligned = aligned && aligned16(arr[q].dgx) && (!arr[q].dgh || aligned16(arr[q].dgh)) && aligned16(arr[q].W_hh);
   if (aligned && rnn_persist_bwd_supported(arr[0].cell, arr[0].T, arr[0].R, arr[0].H, ns))
     return launch_rnn_backward_persist(arr, ns, s);
+  if (aligned && stream_rnn_supported(arr[0].R, arr[0].H, arr[0].cell == CELL_GRU ? 3 : 4)) return rnn_backward_stream(arr, ns, s);
   // ---- one launch per step (for all sequences): dh_{t-1} product with the previous step's cell backward fused in
   const int T = arr[0].T, H = arr[0].H, R = arr[0].R;
   const int G = arr[0].cell == CELL_GRU ? 3 : 4;

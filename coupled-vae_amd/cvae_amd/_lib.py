@@ -57,6 +57,7 @@ SIGNATURES = {
     'cvae_persist_status_set': [I],
     'cvae_projce_workspace': [L, L, L],
     'cvae_split_bf16': [I],
+    'cvae_stream_rnn_min_bytes': [L],
     'cvae_projce_forward': [P, P, P, P, L, I, I, I, I, L, P, P, P, P, P],
     'cvae_projce_backward_workspace': [L, L, L],
     'cvae_projce_backward': [P, P, P, P, L, P, P, I, I, I, I, L, P, P, P, P, P],
@@ -85,7 +86,7 @@ SIGNATURES = {
 }
 _RESTYPE_LONG = {'cvae_encoder_backward_scratch', 'cvae_decoder_backward_scratch', 'cvae_projce_workspace',
                  'cvae_decoder_greedy_scratch', 'cvae_projce_logits_workspace', 'cvae_decoder_beam_scratch',
-                 'cvae_projce_backward_workspace', 'cvae_mi_static_max_rows'}
+                 'cvae_projce_backward_workspace', 'cvae_mi_static_max_rows', 'cvae_stream_rnn_min_bytes'}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync

@@ -306,9 +306,21 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
  * fp32 operand = hi + lo in bf16, product = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation -- relative error ~2^-16 per product.  Measured against fp64 at E = 200, V = 20000: per-sentence loss
  * 2.0e-7 relative (fp32-input MFMA kernel: 1.7e-7), gradients 9.8e-7 for both
- * (tests/test_gpu_kernels.py::test_projce_bf16x3_error).  cvae_split_bf16(0) selects the fp32-input MFMA kernels
- * (v_mfma_f32_32x32x2_f32, ~5x slower); returns the previous setting; env CVAE_SPLIT_BF16=0 sets the default. */
+ * (tests/test_gpu_kernels.py::test_projce_bf16x3_error).  The long-K gradient products (dX = P.W, [dW|db] = P^T.[X|1],
+ * the recurrent layers' weight gradients; 16-byte aligned operands) use a THREE-term split and the six leading
+ * products ("bf16x6", ~2^-24 per product): with two terms the weight gradients were 10x less accurate than the
+ * fp32-input kernel's, with three they are as accurate (scripts/grad_error_modes.py: worst element 7e-7 .. 1.3e-5 of
+ * the tensor's maximum vs the oracle, fp32-input kernels 1.0e-6 .. 2.4e-5).  cvae_split_bf16(0) selects the
+ * fp32-input MFMA kernels (v_mfma_f32_32x32x2_f32) everywhere; returns the previous setting; env CVAE_SPLIT_BF16=0
+ * sets the default. */
 int cvae_split_bf16(int on);
+/* Recurrent layers whose W_hh is far larger than the chip's L2 (R <= 64 rows, H % 64 == 0, split-bf16 on; the scale-up
+ * shape: 67 MB per 2048-unit LSTM) run their per-step kernels in a weight-streaming form: W_hh pre-split once per
+ * sequence into a fragment-ordered bf16 hi / lo image, bf16x3 products, fused cell (forward) / K-split partial
+ * products summed in a fixed order (backward).  The form is used when G*H*H*4 >= the threshold set here (default
+ * 8 MB, env CVAE_STREAM_RNN_MIN_MB; 0 = every supported shape; tests use it to exercise the kernels at small
+ * shapes).  bytes < 0 only queries.  Returns the previous threshold.  No reference counterpart. */
+int64_t cvae_stream_rnn_min_bytes(int64_t bytes);
 
 /* ---- measurement aid, no reference counterpart: opt-in HIP-event timing of the library's
  * own kernels on the launch stream (bench.py's roofline leg).  enable(1) resets and starts

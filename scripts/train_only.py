@@ -1,4 +1,5 @@
-"""Diagnostic: training steps only (Yelp shape), for rocprofv3 --kernel-trace."""
+"""Diagnostic: training steps only (Yelp shape; SHAPE=scaleup BATCH=64 for one GPU's share of the scale-up shape),
+for rocprofv3 --kernel-trace."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
@@ -7,10 +8,10 @@ from cvae_amd import _lib, data, harness
 dev = torch.device('cuda:0'); _lib.init(0)
 cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-shape = data.SHAPES['yelp']
-hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'])
+shape = data.SHAPES[os.environ.get('SHAPE', 'yelp')]
+hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'], batch_size=int(os.environ.get('BATCH', '32')))
 tr = harness.Trainer(hp, dev, seed=0)
-B = 32
+B = int(os.environ.get('BATCH', '32'))
 corpus = data.Corpus(data.synthetic_sentences(B * 8, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
 sort_rows = os.environ.get('SORT_ROWS', '0') == '1'
 batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=sort_rows) for i in range(8)]

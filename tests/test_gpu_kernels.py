@@ -288,6 +288,23 @@ def test_decoder_forward_backward(dev, cell, shape):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
+def test_stream_rnn_kernels(dev, cell):
+    """The weight-streaming split-bf16 step kernels (skinny_stream_kernel: forward with the fused cell, backward as
+    K-split partial products + cell_bwd_parts_kernel), which by default only take recurrent weights of 8 MB and more
+    (the scale-up shape), forced onto small shapes the whole-sequence kernels do not take (more than 32 rows, or H not
+    a multiple of 128): encoder (packed, two directions in lock-step) and decoder, every gradient vs the oracle."""
+    from cvae_amd import _lib
+    prev = _lib.query('cvae_stream_rnn_min_bytes', 0)
+    try:
+        for shape in ((48, 13, 40, 64, 100), (21, 9, 24, 192, 60), (64, 6, 16, 256, 50)):
+            test_encoder_forward_backward(dev, cell, shape)
+        for shape in ((40, 11, 32, 320, 80), (64, 7, 16, 128, 50), (17, 5, 24, 64, 40)):
+            test_decoder_forward_backward(dev, cell, shape)
+    finally:
+        _lib.query('cvae_stream_rnn_min_bytes', prev)
+
+
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
 @pytest.mark.parametrize('shape', [(6, 9, 16, 32, 40, 50), (12, 21, 40, 128, 90, 30)])
 def test_decoder_forward_sorted(dev, cell, shape):
     """cvae_decoder_forward_sorted (sentence-major rows, finished rows skipped) against the plain
