@@ -80,6 +80,16 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // tanh through exp: accurate to ~1e-7 relative over the whole range (no fast-math shortcuts)
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
 
+// Two-instruction forms (v_exp_f32 + v_rcp_f32, about 1 ulp each; absolute error ~1e-7, no denormal or range
+// handling needed: exp2 saturates to 0 / inf and rcp(inf) = 0).  For the many-row evaluation step, whose cell
+// epilogue otherwise spends as many issue cycles on libm's expf / tanhf / IEEE division as its main loop on MFMAs.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.0f);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_TANH: return tanhf_(v);

@@ -199,11 +199,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int RB_BK = 32;
 
+// RB_EXP_* : timing-only diagnostic builds (scripts/build_variant.sh), results are wrong with any of them set
+#ifndef RB_EXP_NOSPLIT
+#define RB_EXP_NOSPLIT 0
+#endif
+#ifndef RB_EXP_NOEPI
+#define RB_EXP_NOEPI 0
+#endif
+#ifndef RB_EXP_NOMFMA
+#define RB_EXP_NOMFMA 0
+#endif
 __device__ __forceinline__ void rb_split(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
   f32x8 v;
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+#if RB_EXP_NOSPLIT
+  union { f32x8 f; bf16x8 h[2]; } u;
+  u.f = v;
+  hi = u.h[0]; lo = u.h[1];
+#else
   hi = __builtin_convertvector(v, bf16x8);
   lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+#endif
 }
 
 template <int CELL>
@@ -242,32 +258,35 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
     sb_slot[i] = r * 4 + (sl ^ ((r >> 2) & 3));
   }
   int kload = 0;
-  f32x4 ra[NTA][2], rb[NTB][2];
-#define RB_STAGE_LOAD()                                                                          \
+  // two register sets: the loads of chunk kt+2 are issued before chunk kt is multiplied and are split / stored to
+  // LDS one iteration later (a single set left them one MFMA phase to land: the kernel ran at the latency of its
+  // staging loads, not at the matrix pipe's rate)
+  f32x4 ra[2][NTA][2], rb[2][NTB][2];
+#define RB_STAGE_LOAD(set)                                                                       \
   do {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < NTA; ++i) {                                            \
-      ra[i][0] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload);                            \
-      ra[i][1] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload + 4);                        \
+      ra[set][i][0] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload);                       \
+      ra[set][i][1] = *reinterpret_cast<const f32x4*>(gA + oa[i] + kload + 4);                   \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NTB; ++i) {                                            \
-      rb[i][0] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload);                            \
-      rb[i][1] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload + 4);                        \
+      rb[set][i][0] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload);                       \
+      rb[set][i][1] = *reinterpret_cast<const f32x4*>(gB + ob[i] + kload + 4);                   \
     }                                                                                            \
     kload += RB_BK;                                                                              \
   } while (0)
-#define RB_STAGE_STORE(buf)                                                                      \
+#define RB_STAGE_STORE(set, buf)                                                                 \
   do {                                                                                           \
     bf16x8* base = sm + (buf) * BUF_SL;                                                          \
     _Pragma("unroll") for (int i = 0; i < NTA; ++i) {                                            \
       bf16x8 hi, lo;                                                                             \
-      rb_split(ra[i][0], ra[i][1], hi, lo);                                                      \
+      rb_split(ra[set][i][0], ra[set][i][1], hi, lo);                                            \
       base[sa_slot[i]] = hi;                                                                     \
       base[A_SL + sa_slot[i]] = lo;                                                              \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NTB; ++i) {                                            \
       if (NB_EXACT || tid + 256 * i < B_SL) {                                                    \
         bf16x8 hi, lo;                                                                           \
-        rb_split(rb[i][0], rb[i][1], hi, lo);                                                    \
+        rb_split(rb[set][i][0], rb[set][i][1], hi, lo);                                          \
         base[2 * A_SL + sb_slot[i]] = hi;                                                        \
         base[2 * A_SL + B_SL + sb_slot[i]] = lo;                                                 \
       }                                                                                          \
@@ -283,32 +302,43 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
   // fragment slots of this lane: A row wave*32 + l31, B row g*32 + l31 (same swizzle term for all: (l31 >> 2) & 3)
   const int arow = wave * 32 + l31, sw = (l31 >> 2) & 3;
   const int nk = H / RB_BK;
-  RB_STAGE_LOAD();
-  RB_STAGE_STORE(0);
+  RB_STAGE_LOAD(0);
+  RB_STAGE_STORE(0, 0);
+  if (nk > 1) RB_STAGE_LOAD(1);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) RB_STAGE_LOAD();
-    const bf16x8* base = sm + buf * BUF_SL;
+  for (int kt0 = 0; kt0 < nk; kt0 += 2) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int sl = (2 * kb + lhi) ^ sw;
-      const bf16x8 ah = base[arow * 4 + sl], al = base[A_SL + arow * 4 + sl];
-      bf16x8 bh[G], bl[G];
+    for (int u = 0; u < 2; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nk) {
+        if (kt + 2 < nk) RB_STAGE_LOAD(u);                 // set u held chunk kt, already in LDS
+        const bf16x8* base = sm + u * BUF_SL;
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        bh[g] = base[2 * A_SL + (g * RL_BU + l31) * 4 + sl];
-        bl[g] = base[2 * A_SL + B_SL + (g * RL_BU + l31) * 4 + sl];
+        for (int kb = 0; kb < 2; ++kb) {
+          const int sl = (2 * kb + lhi) ^ sw;
+          const bf16x8 ah = base[arow * 4 + sl], al = base[A_SL + arow * 4 + sl];
+          bf16x8 bh[G], bl[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            bh[g] = base[2 * A_SL + (g * RL_BU + l31) * 4 + sl];
+            bl[g] = base[2 * A_SL + B_SL + (g * RL_BU + l31) * 4 + sl];
+          }
+#if RB_EXP_NOMFMA
+#pragma unroll
+          for (int g = 0; g < G; ++g) { acc[g][0] += (float)ah[0] * (float)bl[g][0] + (float)al[1] * (float)bh[g][1]; }
+#else
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
+#endif
+        }
+        if (kt + 1 < nk) RB_STAGE_STORE(u ^ 1, u ^ 1);     // chunk kt+1, loaded one iteration ago
+        __syncthreads();
       }
-#pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
     }
-    if (kt + 1 < nk) RB_STAGE_STORE(buf ^ 1);
-    __syncthreads();
   }
 #undef RB_STAGE_LOAD
 #undef RB_STAGE_STORE
@@ -328,6 +358,11 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
       const int m = m0 + wave * 32 + j + 8 * rg + 4 * lhi;
       mm[j] = m;
       const int mc = min(m, p.live - 1);
+#if RB_EXP_NOEPI
+#pragma unroll
+      for (int g = 0; g < G; ++g) x[j][g] = 0.1f * g;
+      hp[j] = 0.5f; cp[j] = 0.25f; (void)mc;
+#else
       const float* xp = p.xproj + (long)((mc / p.xdiv) % p.xmod) * GH + u;
 #pragma unroll
       for (int g = 0; g < G; ++g) x[j][g] = xp[g * H];
@@ -338,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
       }
       hp[j] = p.h_prev[(long)mc * H + u];
       cp[j] = (CELL == CELL_LSTM) ? p.c_prev[(long)mc * H + u] : 0.f;
+#endif
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -347,18 +383,18 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
       for (int g = 0; g < G; ++g) sg[g] = acc[g][r] + bh_[g];
       const long o = (long)mm[j] * H + u;
       if constexpr (CELL == CELL_GRU) {
-        const float rgate = sigmoidf_(x[j][0] + sg[0]);
-        const float zg = sigmoidf_(x[j][1] + sg[1]);
-        const float nn = tanhf_(x[j][2] + rgate * sg[2]);
+        const float rgate = sigmoid_fast(x[j][0] + sg[0]);
+        const float zg = sigmoid_fast(x[j][1] + sg[1]);
+        const float nn = tanh_fast(x[j][2] + rgate * sg[2]);
         if (mm[j] < p.live) p.h_out[o] = (1.f - zg) * nn + zg * hp[j];
       } else {
-        const float ig = sigmoidf_(x[j][0] + sg[0]);
-        const float fg = sigmoidf_(x[j][1] + sg[1]);
-        const float gg = tanhf_(x[j][2] + sg[2]);
-        const float og = sigmoidf_(x[j][3] + sg[3]);
+        const float ig = sigmoid_fast(x[j][0] + sg[0]);
+        const float fg = sigmoid_fast(x[j][1] + sg[1]);
+        const float gg = tanh_fast(x[j][2] + sg[2]);
+        const float og = sigmoid_fast(x[j][3] + sg[3]);
         const float cnew = fg * cp[j] + ig * gg;
         if (mm[j] < p.live) {
-          p.h_out[o] = og * tanhf_(cnew);
+          p.h_out[o] = og * tanh_fast(cnew);
           p.c_out[o] = cnew;
         }
       }

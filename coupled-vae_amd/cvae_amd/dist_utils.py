@@ -47,6 +47,18 @@ def allreduce_mean_(flat, n_buckets=1):
     return flat
 
 
+def allreduce_sum_async(flat):
+    """Starts the SUM all-reduce of a flat buffer and returns a handle to wait on (None when it already completed:
+    gloo on device buffers, staged through the host).  With nccl (RCCL) the collective runs on its own stream behind
+    the work queued so far on the current stream, i.e. it overlaps whatever the caller enqueues next."""
+    if flat.is_cuda and dist.get_backend() == 'gloo':
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat.copy_(h)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def shard_batches(n_batches, r=None, w=None):
     """Indices of the batches rank r evaluates (round-robin)."""
     r = rank() if r is None else r

@@ -112,6 +112,90 @@ class FlatAdam(object):
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0
         self.lr = hp.lr
+        self.offsets = []
+        off = 0
+        for p in uniq:
+            self.offsets.append(off)
+            off += pad4(p.numel())
+        self.buckets = None            # data-parallel gradient buckets (arm_buckets)
+        self.hooks_live = False        # hooks act only inside Trainer.forward_backward's backward pass
+        self.issued_early = 0          # buckets of the last step whose collective started inside the backward pass
+        self._had_grad = None
+
+    # ---- data-parallel training: bucketed all-reduce overlapped with the backward pass.
+    # (The reference is single-process: SURVEY 8e.  Constraint kept: the reduction completes before the clip,
+    # CV/Experiment.py:509-522.)  The arena is cut into contiguous buckets of about `bucket_bytes`; a bucket is
+    # issued from the autograd hook of the LAST of its parameters to receive a gradient, so the collective of the
+    # parameters whose gradients come first (ToVocab, the decoders) runs while the rest of the backward pass
+    # (encoder, embedding) is still computing.  Which parameters receive a gradient at all is learnt from the
+    # first (un-bucketed) step: BoW and PosteriorGaussianCouple.toSigma never do (None in the reference too).
+    def arm_buckets(self, bucket_bytes):
+        expected = [i for i, had in enumerate(self._had_grad or []) if had]
+        if not expected or bucket_bytes <= 0:
+            return
+        self.buckets, cur = [], None
+        for i in expected:
+            lo = self.offsets[i]
+            hi = lo + self.views[i].numel()
+            if cur is None or (hi - cur['lo']) * 4 > bucket_bytes:
+                cur = {'lo': lo, 'hi': hi, 'members': [], 'arrived': 0, 'work': None, 'fired': False}
+                self.buckets.append(cur)
+            cur['hi'] = hi
+            cur['members'].append(i)
+        # every bucket also carries the (zero-gradient) padding and never-touched segments up to the next bucket
+        for k, b in enumerate(self.buckets):
+            b['hi'] = self.buckets[k + 1]['lo'] if k + 1 < len(self.buckets) else self.grads.numel()
+        self.buckets[0]['lo'] = 0
+        owner = {}
+        for b in self.buckets:
+            for i in b['members']:
+                owner[i] = b
+        for i, p in enumerate(self.views):
+            if i in owner:
+                p.register_post_accumulate_grad_hook(self._make_hook(owner[i]))
+
+    def _make_hook(self, bucket):
+        def hook(param):
+            if not self.hooks_live or self.buckets is None or bucket['fired']:
+                return
+            bucket['arrived'] += 1
+            if bucket['arrived'] == len(bucket['members']):
+                self._fire(bucket)
+        return hook
+
+    def _fire(self, bucket):
+        src, dst = [], []
+        for i in bucket['members']:
+            p, g = self.views[i], self.gviews[i]
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                src.append(p.grad)
+                dst.append(g)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for i in bucket['members']:
+            self.views[i].grad = self.gviews[i]
+        bucket['work'] = dist_utils.allreduce_sum_async(self.grads[bucket['lo']:bucket['hi']])
+        bucket['fired'] = True
+        self.issued_early += 1
+
+    def finish_allreduce(self, world):
+        """After backward: gathers what the hooks did not, reduces every bucket not issued yet, waits for all of
+        them and turns the sums into means.  Un-armed (first step, or dp_bucket_bytes = 0): one all-reduce."""
+        self.hooks_live = False
+        if self.buckets is None:
+            self._had_grad = [p.grad is not None for p in self.views]
+        self.gather_grads()
+        if self.buckets is None:
+            dist_utils.allreduce_mean_(self.grads)
+            return
+        for b in self.buckets:
+            if not b['fired']:
+                b['work'] = dist_utils.allreduce_sum_async(self.grads[b['lo']:b['hi']])
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+            b['work'], b['fired'], b['arrived'] = None, False, 0
+        self.grads.mul_(1.0 / world)
 
     def zero_grad(self):
         """Gradients are produced outside the arena and gathered once after backward (gather_grads):
@@ -150,6 +234,7 @@ class Trainer(object):
         self.iter_num = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self._armed = False
 
     # ---- one training iteration: CV/Experiment.py:646-775 / CC/Experiment.py:318-428
     def losses(self, batch):
@@ -206,12 +291,19 @@ class Trainer(object):
             res = self.losses(batch)
         finally:
             settings.restore_row_order = keep
+        self.opt.hooks_live = self.world > 1
+        self.opt.issued_early = 0
         res['tot'].backward()
-        self.opt.gather_grads()
         if self.world > 1:
             # the batch mean over equal per-rank batches = mean of per-rank gradients; must
-            # complete before the clip (Experiment.py:515 clips the full-batch gradient)
-            dist_utils.allreduce_mean_(self.opt.grads)
+            # complete before the clip (Experiment.py:515 clips the full-batch gradient).  Buckets whose
+            # gradients were complete earlier in the backward pass are already in flight (FlatAdam.arm_buckets)
+            self.opt.finish_allreduce(self.world)
+            if self.opt.buckets is None and settings.dp_bucket_bytes > 0 and not self._armed:
+                self._armed = True
+                self.opt.arm_buckets(settings.dp_bucket_bytes)
+        else:
+            self.opt.gather_grads()
         return res
 
     def check_kernels(self, sync=False):

@@ -1,4 +1,5 @@
 """Process-wide switches of the host mirror (the reference keeps these in config.Config)."""
+import os
 
 
 class _Settings(object):
@@ -15,6 +16,10 @@ class _Settings(object):
     #                           (modules.RowOrder; per-row outputs come back in the caller's order)
     restore_row_order = True  # False: per-row outputs of forward() stay in the sorted order (callers that only
     #                           take batch means, i.e. harness.Trainer, save the un-permute launches)
+    dp_bucket_bytes = int(os.environ.get('CVAE_DP_BUCKET_MB', '16')) << 20   # (env CVAE_DP_BUCKET_MB)
+    # data-parallel training: the gradient arena is all-reduced in buckets of about this size,
+    #                              each issued (async, on the collective's own stream) as soon as the backward pass has
+    #                              produced every gradient in it; 0: one blocking all-reduce after the backward pass
 
 
 settings = _Settings()

@@ -3,7 +3,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
 import torch
-from cvae_amd import _lib, data, harness
+from cvae_amd import _lib, data, harness, settings
+settings.iw_max_rows = int(os.environ.get('IW_MAX_ROWS', settings.iw_max_rows))
 dev = torch.device('cuda:0'); _lib.init(0)
 cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 500

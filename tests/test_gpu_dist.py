@@ -85,7 +85,8 @@ def _train_worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from cvae_amd import _lib, data, harness, modules
+        from cvae_amd import _lib, data, harness, modules, settings
+        settings.dp_bucket_bytes = 48 << 10          # several buckets at this small shape (default: 16 MB)
         dev = torch.device('cuda:0')
         _lib.init(0)
         V, E, H, Z, Bl = _DP_SHAPE
@@ -99,12 +100,23 @@ def _train_worker(rank, world, port, q):
             batch = harness.text_batch(c, range(rank * Bl, (rank + 1) * Bl), dev)      # this rank's sentences
             eps = torch.randn(world * Bl, Z, generator=torch.Generator().manual_seed(13))
             mine = eps[rank * Bl:(rank + 1) * Bl].unsqueeze(0)
-            tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1
-            modules.set_noise_source(modules.ReplayNoise({'eps': [mine], 'eps_couple': [mine]}))
-            try:
-                res = tr.forward_backward(batch)                    # includes the all-reduce (mean) of the arena
-            finally:
-                modules.set_noise_source(None)
+            # pass 0: one blocking all-reduce, learns which parameters receive gradients and arms the buckets;
+            # pass 1 (same inputs, weights untouched in between): the bucketed form, collectives issued from the
+            # autograd hooks while the backward pass is still running.  Both must give the same reduced gradient.
+            seen = []
+            for it in range(2):
+                tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1
+                modules.set_noise_source(modules.ReplayNoise({'eps': [mine], 'eps_couple': [mine]}))
+                try:
+                    res = tr.forward_backward(batch)                # includes the all-reduce (mean) of the arena
+                finally:
+                    modules.set_noise_source(None)
+                seen.append(tr.opt.grads.detach().clone())
+            assert tr.opt.buckets is not None and len(tr.opt.buckets) >= 3, 'buckets not armed'
+            assert tr.opt.issued_early >= 2, 'no bucket was issued from inside the backward pass'
+            # (not bit-equal: the embedding gradient is scattered with float atomics, whose order varies run to run)
+            err = float((seen[0] - seen[1]).abs().max() / seen[0].abs().max())
+            assert err < 2e-6, 'bucketed all-reduce differs from the single collective: %.3g' % err
             sd = tr.model.state_dict(keep_vars=True)
             grads = {k: v.grad.detach().cpu().numpy().copy() for k, v in sd.items() if v.grad is not None}   # numpy: pickled by value
             tr.opt.step()
