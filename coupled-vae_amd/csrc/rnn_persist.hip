@@ -133,8 +133,20 @@ __device__ __forceinline__ void publish(unsigned* flags, unsigned epoch) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
+typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef float f32x8p __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)v;
+  const float r1 = v - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
 // --------------------------------------------------------------------------------------- forward
-template <int CELL>
+// BF: the gate product on the bf16 matrix pipe, two-term split ("bf16x3", the forward products' form: ce_fast.hip).
+// Every wave owns 32 of K = one v_mfma_f32_16x16x32_bf16 K block (NW = H / 32): three MFMAs of 16 cycles per row
+// fragment instead of eight v_mfma_f32_16x16x4_f32 of 32; W_hh's fragments are split once, h as it arrives.
+template <int CELL, bool BF>
 __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
   constexpr int NC = P_HU * G;                       // live gate columns of this block (12 / 16)
@@ -158,19 +170,29 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
   // W_hh fragments (B operand of 16x16x4: lane = column l15, k group kq), resident for all T steps.
   // Column c = u*G + g of the block is gate row g*H + u0 + u; MFMA step s of this lane uses
   // k = wave*KW + kq*NSL + s (the same permutation of K is applied to h below).
-  float w[16];
+  float w[BF ? 1 : 16];
+  bf16x8p wbh, wbl;                                    // BF: k = wave*32 + kq*8 .. +7 of this lane's column (NSL == 8)
 #pragma unroll
-  for (int s = 0; s < 16; ++s) w[s] = 0.f;
+  for (int s = 0; s < (BF ? 1 : 16); ++s) w[s] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { wbh[e] = (__bf16)0.f; wbl[e] = (__bf16)0.f; }
   const int kbase = wave * KW + kq * NSL;
   if (wave < NW && l15 < NC) {
     const int u = l15 / G, g = l15 % G;
     const float* wr = q.W_hh + (long)(g * H + u0 + u) * H + kbase;
+    if constexpr (BF) {
+      const float4 v0 = *reinterpret_cast<const float4*>(wr), v1 = *reinterpret_cast<const float4*>(wr + 4);
+      const f32x8p v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      wbh = __builtin_convertvector(v, bf16x8p);
+      wbl = __builtin_convertvector(v - __builtin_convertvector(wbh, f32x8p), bf16x8p);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (4 * j < NSL) {
-        const float4 v = *reinterpret_cast<const float4*>(wr + 4 * j);
-        w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-      }
+      for (int j = 0; j < 4; ++j)
+        if (4 * j < NSL) {
+          const float4 v = *reinterpret_cast<const float4*>(wr + 4 * j);
+          w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        }
+    }
   }
 
   // cell threads: (row, unit) = (tid >> 2, tid & 3); their state lives in registers
@@ -224,15 +246,31 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
           if (4 * j < NSL && row < R) a[f][j] = ld16_sc1(rs_hs, in_slot * RH + (long)row * H + kbase + 4 * j);
         }
       }
+      if constexpr (BF) {
+        bf16x8p ah[2], al[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * j < NSL) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][j][e], w[4 * j + e], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][j][e], w[4 * j + e], acc[1], 0, 0, 0);
-          }
+        for (int f = 0; f < 2; ++f) {
+          const f32x8p v = {a[f][0][0], a[f][0][1], a[f][0][2], a[f][0][3], a[f][1][0], a[f][1][1], a[f][1][2], a[f][1][3]};
+          ah[f] = __builtin_convertvector(v, bf16x8p);
+          al[f] = __builtin_convertvector(v - __builtin_convertvector(ah[f], f32x8p), bf16x8p);
         }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], wbh, acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], wbl, acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], wbh, acc[f], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * j < NSL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][j][e], w[4 * j + e], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][j][e], w[4 * j + e], acc[1], 0, 0, 0);
+            }
+          }
+      }
     }
     P_STAMP(2);
     // C layout of 16x16x4: acc[f][r] = (row 16f + 4*kq + r, column l15)
@@ -331,7 +369,14 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
 // its 32 x H partial and gathers 32 x H of others' partials either way), so the exchange volume of a
 // sequence is (H / HU) x 2 x 32 x H x 4 B per step: HU = 8 halves it (and the number of flags to poll) at
 // twice the -- small -- MFMA and cell work per block.
-template <int CELL, int HU>
+// BF: the product on the bf16 matrix pipe with a three-term split of both operands ("bf16x6", as gemm_wide.hip:
+// fp32-level accuracy).  The block's K is 4G..8G <= 32 = ONE v_mfma_f32_16x16x32_bf16 K block, so a (row fragment,
+// column fragment) pair costs 6 x 16 cycles instead of 8 x 32 for v_mfma_f32_16x16x4_f32: the product phase was
+// 1.7 us of the 6.1 us step.  dG is split ONCE, by the cell threads as they write it to LDS (all 16 waves read the
+// same A fragments); W_hh's slice is split into register fragments before the loop.
+constexpr int DGS_LD = 40;          // bf16 per dG row in LDS: 80 B, the 16 rows of a b128 fragment read cover all 64 banks
+
+template <int CELL, int HU, bool BF>
 __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) {
   constexpr int G = CELL == CELL_GRU ? 3 : 4;
   constexpr int NC = HU * G;                         // live K of this block's slice (12 / 16 / 24 / 32)
@@ -341,7 +386,8 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   constexpr int PIECE = 32 * HU;                     // floats one block sends to one destination per step
   constexpr int NGRP = P_THREADS / (32 * GPR);       // source groups after the gather's first pass
   extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[32][H + 4]  (aliased: red[1024][4])
-  __shared__ float dGl[32][LDG];                                   // dG of this block: [row][u*G + g]
+  __shared__ float dGl[BF ? 1 : 32][LDG];                          // dG of this block: [row][u*G + g]
+  __shared__ __attribute__((aligned(16))) __bf16 dGs[BF ? 3 : 1][BF ? 32 * DGS_LD : 8];   // BF: hi | mid | lo, [row][k]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
@@ -361,20 +407,39 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   const long ex_par = (long)nb * nb * PIECE;
   const __amdgpu_buffer_rsrc_t rs_ex = make_rsrc(p.exch + (size_t)blockIdx.y * 2 * ex_par);
   if (tid == 0) s_abort = 0;
-  for (int i = tid; i < 32 * LDG; i += P_THREADS) (&dGl[0][0])[i] = 0.f;
+  if constexpr (BF) {
+    for (int i = tid; i < 3 * 32 * DGS_LD; i += P_THREADS) (&dGs[0][0])[i] = (__bf16)0.f;
+  } else {
+    for (int i = tid; i < 32 * LDG; i += P_THREADS) (&dGl[0][0])[i] = 0.f;
+  }
 
   // W_hh[gate rows of U, :] as B fragments: wave w owns output column fragments w, w + 16, ...
   // (H / 16 fragments); fragment nf, MFMA step s: lane (n = l15, kq) holds W_hh[row(4s + kq)][16*nf + l15]
   const int nfr = H / 16;
-  float w[2][KS];
+  float w[2][BF ? 1 : KS];
+  bf16x8p wb[2][3];                                      // BF: lane (n = l15, kq) holds k = 8*kq .. 8*kq + 7 (zero past NC)
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
+    const int nf = wave + 16 * j;
+    if constexpr (BF) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int nf = wave + 16 * j, k = 4 * s + kq;
-      w[j][s] = 0.f;
-      if (nf < nfr && k < NC) w[j][s] = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+      for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kq + e;
+        float v = 0.f;
+        if (nf < nfr && k < NC) v = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+        __bf16 h_, m_, l_;
+        split3(v, h_, m_, l_);
+        wb[j][0][e] = h_; wb[j][1][e] = m_; wb[j][2][e] = l_;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + kq;
+        w[j][s] = 0.f;
+        if (nf < nfr && k < NC) w[j][s] = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+      }
     }
+  }
 
   const bool cellt = tid < 32 * HU;
   const int crow = tid / HU, cu = tid % HU, cn = u0 + cu;
@@ -461,7 +526,17 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
       }
       // A operand of the product: the h-side gradients
 #pragma unroll
-      for (int g = 0; g < G; ++g) dGl[crow][cu * G + g] = (CELL == CELL_GRU) ? oh[g] : ox[g];
+      for (int g = 0; g < G; ++g) {
+        const float v = (CELL == CELL_GRU) ? oh[g] : ox[g];
+        if constexpr (BF) {
+          __bf16 h_, m_, l_;
+          split3(v, h_, m_, l_);
+          const int o = crow * DGS_LD + cu * G + g;
+          dGs[0][o] = h_; dGs[1][o] = m_; dGs[2][o] = l_;
+        } else {
+          dGl[crow][cu * G + g] = v;
+        }
+      }
       // global copies for the weight gradients: 16-byte stores per (row, gate, 4 units)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -486,7 +561,35 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     // this step's bound have an all-zero dG: a 16-row fragment wholly past it is neither multiplied nor
     // written (its part of the tile is not published either).
     const int rb_cur = row_bound(t);
-    {
+    if constexpr (BF) {
+      bf16x8p a[2][3];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+          a[f][tm] = *reinterpret_cast<const bf16x8p*>(&dGs[tm][(16 * f + l15) * DGS_LD + 8 * kq]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nf = wave + 16 * j;
+        if (nf < nfr) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            if (rb_cur > 16 * f) {
+              // small terms first: mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi
+              f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][1], wb[j][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][2], wb[j][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][1], wb[j][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][0], acc, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tile[(16 * f + 4 * kq + r) * LDT + 16 * nf + l15] = acc[r];
+            }
+          }
+        }
+      }
+    } else {
       float a[2][KS];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -611,6 +714,8 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch
     if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
   for (int nw = 16; nw >= 2 && !p.nw; nw >>= 1)
     if (p.H % (16 * nw) == 0 && p.H / nw <= 64) p.nw = nw;
+  const bool bf = split_bf16_enabled() && p.H % 32 == 0 && p.H / 32 <= 16;
+  if (bf) p.nw = p.H / 32;                               // one 32-wide bf16 MFMA K block per wave
   CVAE_REQUIRE(p.nw >= 1 && p.nw <= 16 && p.H % p.nw == 0 && (p.H / p.nw) % 16 == 0 && p.H / p.nw <= 64,
                "rnn_forward_persist: H=%d does not split over the block's waves", p.H);
   p.flags = sync; p.status = status; p.stamps = persist_stamps();
@@ -623,8 +728,13 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch
   }
   const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
   ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * (a[0].cell == CELL_GRU ? 3.0 : 4.0) * p.H * p.H);
-  if (a[0].cell == CELL_GRU) hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_GRU>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(rnn_fwd_persist_kernel<CELL_LSTM>, grid, block, 0, s, p);
+  if (bf) {
+    if (a[0].cell == CELL_GRU) hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_GRU, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_LSTM, true>), grid, block, 0, s, p);
+  } else {
+    if (a[0].cell == CELL_GRU) hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_GRU, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_LSTM, false>), grid, block, 0, s, p);
+  }
   CVAE_LAUNCH_CHECK("rnn_fwd_persist_kernel");
   return 0;
 }
@@ -680,10 +790,14 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   const dim3 grid(nb, ns), block(P_THREADS);
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4>),
-                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 4>),
-                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 8>),
-                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 8>)};
+    const void* fns[8] = {reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4, false>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 4, false>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 8, false>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 8, false>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4, true>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 4, true>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 8, true>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 8, true>)};
     for (const void* f : fns)
       CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                          "persist bwd LDS attribute"));
@@ -691,12 +805,20 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   }
   ProfScope prof(PK_RNN_PERSIST_BWD, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
   const bool gru = a[0].cell == CELL_GRU;
-  if (hu == 8) {
-    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 8>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 8>), grid, block, lds, s, p);
+  if (split_bf16_enabled()) {
+    if (hu == 8) {
+      if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 8, true>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 8, true>), grid, block, lds, s, p);
+    } else {
+      if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 4, true>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 4, true>), grid, block, lds, s, p);
+    }
+  } else if (hu == 8) {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 8, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 8, false>), grid, block, lds, s, p);
   } else {
-    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 4>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 4>), grid, block, lds, s, p);
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 4, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 4, false>), grid, block, lds, s, p);
   }
   CVAE_LAUNCH_CHECK("rnn_bwd_persist_kernel");
   return 0;
