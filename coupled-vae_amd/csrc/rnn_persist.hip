@@ -374,7 +374,6 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
 // column fragment) pair costs 6 x 16 cycles instead of 8 x 32 for v_mfma_f32_16x16x4_f32: the product phase was
 // 1.7 us of the 6.1 us step.  dG is split ONCE, by the cell threads as they write it to LDS (all 16 waves read the
 // same A fragments); W_hh's slice is split into register fragments before the loop.
-constexpr int DGS_LD = 40;          // bf16 per dG row in LDS: 80 B, the 16 rows of a b128 fragment read cover all 64 banks
 
 template <int CELL, int HU, bool BF>
 __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) {
@@ -386,6 +385,8 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   constexpr int PIECE = 32 * HU;                     // floats one block sends to one destination per step
   constexpr int NGRP = P_THREADS / (32 * GPR);       // source groups after the gather's first pass
   extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[32][H + 4]  (aliased: red[1024][4])
+  constexpr int NKB = (NC + 31) / 32;                // BF: 32-wide MFMA K blocks (1; 2 at HU = 16)
+  constexpr int DGS_LD = 32 * NKB + 8;               // bf16 per dG row in LDS (80 / 144 B): the 16 rows of a b128 fragment read cover all 64 banks
   __shared__ float dGl[BF ? 1 : 32][LDG];                          // dG of this block: [row][u*G + g]
   __shared__ __attribute__((aligned(16))) __bf16 dGs[BF ? 3 : 1][BF ? 32 * DGS_LD : 8];   // BF: hi | mid | lo, [row][k]
   __shared__ int s_abort;
@@ -417,20 +418,22 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
   // (H / 16 fragments); fragment nf, MFMA step s: lane (n = l15, kq) holds W_hh[row(4s + kq)][16*nf + l15]
   const int nfr = H / 16;
   float w[2][BF ? 1 : KS];
-  bf16x8p wb[2][3];                                      // BF: lane (n = l15, kq) holds k = 8*kq .. 8*kq + 7 (zero past NC)
+  bf16x8p wb[2][NKB][3];                                 // BF: lane (n = l15, kq) holds k = 32*kb + 8*kq .. + 7 (zero past NC)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nf = wave + 16 * j;
     if constexpr (BF) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = 8 * kq + e;
-        float v = 0.f;
-        if (nf < nfr && k < NC) v = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
-        __bf16 h_, m_, l_;
-        split3(v, h_, m_, l_);
-        wb[j][0][e] = h_; wb[j][1][e] = m_; wb[j][2][e] = l_;
-      }
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 32 * kb + 8 * kq + e;
+          float v = 0.f;
+          if (nf < nfr && k < NC) v = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+          __bf16 h_, m_, l_;
+          split3(v, h_, m_, l_);
+          wb[j][kb][0][e] = h_; wb[j][kb][1][e] = m_; wb[j][kb][2][e] = l_;
+        }
     } else {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -562,27 +565,33 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     // written (its part of the tile is not published either).
     const int rb_cur = row_bound(t);
     if constexpr (BF) {
-      bf16x8p a[2][3];
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int f = 0; f < 2; ++f) {
+        if (rb_cur > 16 * f) {
+          bf16x8p a[NKB][3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm)
-          a[f][tm] = *reinterpret_cast<const bf16x8p*>(&dGs[tm][(16 * f + l15) * DGS_LD + 8 * kq]);
+          for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nf = wave + 16 * j;
-        if (nf < nfr) {
+            for (int tm = 0; tm < 3; ++tm)
+              a[kb][tm] = *reinterpret_cast<const bf16x8p*>(&dGs[tm][(16 * f + l15) * DGS_LD + 32 * kb + 8 * kq]);
 #pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            if (rb_cur > 16 * f) {
+          for (int j = 0; j < 2; ++j) {
+            const int nf = wave + 16 * j;
+            if (nf < nfr) {
               // small terms first: mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi
               f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][1], wb[j][1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][2], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][2], wb[j][0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][1], wb[j][0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][0], wb[j][0], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], wb[j][kb][1], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][2], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][2], wb[j][kb][0], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][1], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], wb[j][kb][0], acc, 0, 0, 0);
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][0], acc, 0, 0, 0);
 #pragma unroll
               for (int r = 0; r < 4; ++r) tile[(16 * f + 4 * kq + r) * LDT + 16 * nf + l15] = acc[r];
             }
@@ -765,8 +774,10 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   p.flags = sync; p.status = status; p.stamps = persist_stamps();
   const int G = a[0].cell == CELL_GRU ? 3 : 4;
   static int hu_env = 0;                       // CVAE_PERSIST_BWD_HU=4: the 4-unit blocks (more, thinner blocks)
-  if (!hu_env) { const char* e = getenv("CVAE_PERSIST_BWD_HU"); hu_env = (e && atoi(e) == 4) ? 4 : 8; }
-  const int hu = (hu_env == 8 && p.H % 8 == 0) ? 8 : 4;
+  if (!hu_env) { const char* e = getenv("CVAE_PERSIST_BWD_HU"); hu_env = e ? atoi(e) : 8; if (hu_env != 4 && hu_env != 16) hu_env = 8; }
+  // 16-unit blocks (a quarter of the blocks and flags of the 4-unit form; CVAE_PERSIST_BWD_HU=16) only with the bf16
+  // product (K = 64: two K blocks).  Measured slower than 8 (training step 7.26 vs 7.08 ms): opt-in, kept for larger H
+  const int hu = (hu_env == 16 && p.H % 16 == 0 && split_bf16_enabled()) ? 16 : ((hu_env >= 8 && p.H % 8 == 0) ? 8 : 4);
   const int nb = p.H / hu;
   CVAE_REQUIRE(p.H % 16 == 0 && p.H / 16 <= 32 && nb <= P_MAXB, "rnn_backward_persist: H=%d", p.H);
   CVAE_TRY(persist_exch(s, (long)SKINNY_MAX_BATCH * 2 * nb * nb * 32 * hu, &p.exch));
@@ -790,7 +801,9 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   const dim3 grid(nb, ns), block(P_THREADS);
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[8] = {reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4, false>),
+    const void* fns[10] = {reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 16, true>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 16, true>),
+                          reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 4, false>),
                           reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 4, false>),
                           reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_GRU, 8, false>),
                           reinterpret_cast<const void*>(&rnn_bwd_persist_kernel<CELL_LSTM, 8, false>),
@@ -805,7 +818,10 @@ int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
   }
   ProfScope prof(PK_RNN_PERSIST_BWD, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
   const bool gru = a[0].cell == CELL_GRU;
-  if (split_bf16_enabled()) {
+  if (hu == 16) {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 16, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 16, true>), grid, block, lds, s, p);
+  } else if (split_bf16_enabled()) {
     if (hu == 8) {
       if (gru) hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_GRU, 8, true>), grid, block, lds, s, p);
       else hipLaunchKernelGGL((rnn_bwd_persist_kernel<CELL_LSTM, 8, true>), grid, block, lds, s, p);
