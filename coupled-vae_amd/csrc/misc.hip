@@ -532,11 +532,12 @@ int launch_linear_bwd_small(int M, int N, int K, int act, const float* x, const 
   return 0;
 }
 
-// ---- a11: loss assembly (CV/Experiment.py:753-757): batch means of up to four per-sentence terms and their
+// ---- a11: loss assembly (CV/Experiment.py:753-757): batch means of up to six per-sentence terms and their
 // weighted sum, in one launch (the torch expression is ~20 tiny kernels forward and ~10 backward).
-struct LossTerms { const float* t[4]; float* d[4]; float coef[4]; };
+constexpr int LOSS_MAX_TERMS = 6;      // seq, kl, seq_couple, couple, bow + one spare
+struct LossTerms { const float* t[LOSS_MAX_TERMS]; float* d[LOSS_MAX_TERMS]; float coef[LOSS_MAX_TERMS]; };
 __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms a, int n, int B, float* __restrict__ out) {
-  __shared__ float red[4][4];
+  __shared__ float red[LOSS_MAX_TERMS][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float tot = 0.f;
   for (int i = 0; i < n; ++i) {
@@ -562,7 +563,7 @@ __global__ void loss_assemble_bwd_kernel(LossTerms a, int n, int B, const float*
   a.d[i][b] = gtot[0] * a.coef[i] / (float)B;
 }
 int launch_loss_assemble(int n, int B, const float* const* terms, const float* coef, float* out, hipStream_t s) {
-  CVAE_REQUIRE(n >= 1 && n <= 4 && B > 0 && terms && coef && out, "loss_assemble: bad arguments (n=%d)", n);
+  CVAE_REQUIRE(n >= 1 && n <= LOSS_MAX_TERMS && B > 0 && terms && coef && out, "loss_assemble: bad arguments (n=%d)", n);
   LossTerms a = {};
   for (int i = 0; i < n; ++i) {
     CVAE_REQUIRE(terms[i], "loss_assemble: null term %d", i);
@@ -573,7 +574,7 @@ int launch_loss_assemble(int n, int B, const float* const* terms, const float* c
   return 0;
 }
 int launch_loss_assemble_bwd(int n, int B, const float* gtot, const float* coef, float* const* dterms, hipStream_t s) {
-  CVAE_REQUIRE(n >= 1 && n <= 4 && B > 0 && gtot && coef && dterms, "loss_assemble_backward: bad arguments (n=%d)", n);
+  CVAE_REQUIRE(n >= 1 && n <= LOSS_MAX_TERMS && B > 0 && gtot && coef && dterms, "loss_assemble_backward: bad arguments (n=%d)", n);
   LossTerms a = {};
   for (int i = 0; i < n; ++i) {
     CVAE_REQUIRE(dterms[i], "loss_assemble_backward: null gradient %d", i);

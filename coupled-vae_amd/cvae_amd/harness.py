@@ -24,7 +24,7 @@ class HParams(object):
     def __init__(self, model='vae-couple', cell='gru', V=10002, E=200, H=128, Z=32, dropout=0.2, lr=1e-3,
                  beta1=0.9, beta2=0.999, clip_norm=30.0, kl_annealing=True, annealing_start=2000,
                  annealing_step=40000, lambda_couple=0.1, lambda_seq_couple=1.0, euclidean_dist=False,
-                 max_len=200, batch_size=32, pad_id=0, beta=0.8, cyc_M=4, cyc_R=0.5, lambda_fb=6.0):
+                 max_len=200, batch_size=32, pad_id=0, beta=0.8, cyc_M=4, cyc_R=0.5, lambda_fb=6.0, lambda_BoW=0.0):
         """model: vae | vae-couple | cvae | cvae-couple, or a sibling on the same modules:
         dae, beta-vae[-couple] (lambda_KL capped at beta), cyc-anneal-vae[-couple] (cyclic schedule, cyc_M
         cycles with ramp fraction cyc_R), surprising-fix[-couple] (free bits lambda_fb)."""
@@ -257,9 +257,9 @@ class Trainer(object):
             out = m(go=batch['go'], sent_len=batch['len'], bare=batch['bare'])
             eos = batch['eos']
             if hp.is_couple():
-                logits, post, _, _, logits_c, init, init_c = out
+                logits, post, _, bow_logits, logits_c, init, init_c = out
             else:
-                logits, post, _, _ = out
+                logits, post, _, bow_logits = out
             if hp.model.startswith('surprising-fix'):  # free bits, CV/Experiment.py:1141-1142
                 kl = ops.kl_free_bits(post.loc, post.scale, hp.lambda_fb / hp.Z)
             else:
@@ -274,6 +274,14 @@ class Trainer(object):
             coef += [hp.lambda_seq_couple, hp.lambda_couple]
             terms += [m.criterionSeq(logits_c, eos, keep_batch=True),
                       ops.couple_loss(init, init_c, hp.Z, hp.euclidean_dist)]
+        if hp.lambda_BoW > 0 and not hp.is_dialog():
+            # bag-of-words loss (CV/Experiment.py:703-706, 713-715, 737-740): cross-entropy of BoW(z) against every
+            # token of the sentence, per sentence divided by its length; enters the total only once lambda_KL > 1e-5
+            L = batch['bare'].shape[1]
+            bow = m.criterionSeq(bow_logits.unsqueeze(1).expand(-1, L, -1), batch['bare'], keep_batch=True)
+            names.append('bow')
+            coef.append(hp.lambda_BoW if lam > 1e-5 else 0.0)
+            terms.append(bow / batch['len'].to(bow.dtype))
         tot, means = ops.loss_assemble(terms, coef)
         res = {nm: means[i] for i, nm in enumerate(names)}
         res['tot'] = tot.view(())

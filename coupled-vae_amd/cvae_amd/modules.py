@@ -128,6 +128,11 @@ def _train_order(length):
     return RowOrder(length) if (settings.sort_train_rows and length.numel() > 1) else None
 
 
+def _left_sorted(ro):
+    """The RowOrder per-row outputs were left in (restore_row_order off), or None when they are in the caller's order."""
+    return ro if (ro is not None and not ro.restore) else None
+
+
 def set_noise_source(src):
     global _noise
     _noise = src if src is not None else NoiseSource()
@@ -150,6 +155,7 @@ class LazyLogits(object):
     def __init__(self, final, weight, bias, n_sent, order=None):
         self.final, self.weight, self.bias, self.n_sent = final, weight, bias, n_sent
         self.order = order            # RowOrder the rows of `final` are in (None: the caller's order)
+        self.always_restore = False   # True: per-sentence sums go back to the caller's order whatever the settings say
 
     @property
     def shape(self):
@@ -159,6 +165,38 @@ class LazyLogits(object):
     def materialize(self):
         out = ops.logits_bt(self.final.detach(), self.weight.detach(), self.bias.detach())
         return out if self.order is None else out.index_select(0, self.order.res_idx)
+
+
+class LazyBoW(object):
+    """What forward() returns in place of BoW_logits = BoW(z) (CV/Modules/vae.py / vae_couple.py:724): the latent
+    and the BoW head's parameters.  The reference's caller does
+    `BoW_logits.unsqueeze(1).expand(-1, L, -1)` and hands the result to criterionSeq with the bare tokens as
+    targets (CV/Experiment.py:703-706): those two calls turn this object into a LazyLogits whose rows are z repeated
+    over the L positions, so the bag-of-words loss runs through the same fused projection + cross-entropy kernel
+    and the (B, L, V) tensor is never formed."""
+
+    def __init__(self, z, weight, bias, order=None):
+        self.z, self.weight, self.bias = z, weight, bias
+        self.order = order            # RowOrder the rows of z were LEFT in (settings.restore_row_order = False), else None
+
+    @property
+    def shape(self):
+        return torch.Size([self.z.shape[0], self.weight.shape[0]])
+
+    def unsqueeze(self, dim):
+        assert dim == 1, 'LazyBoW supports the reference\'s unsqueeze(1).expand(-1, L, -1) only'
+        return self
+
+    def expand(self, *sizes):
+        L = int(sizes[1])
+        B, Z = self.z.shape
+        final = self.z.unsqueeze(0).expand(L, B, Z).contiguous()       # time-major rows, as a decoder's `final`
+        out = LazyLogits(final, self.weight, self.bias, B, order=self.order)
+        out.always_restore = True     # the caller divides the per-sentence sums by ITS sent_len: caller's row order
+        return out
+
+    def materialize(self):
+        return torch.nn.functional.linear(self.z.detach(), self.weight.detach(), self.bias.detach())
 
 
 # --------------------------------------------------------------------------- SeqLoss
@@ -172,8 +210,9 @@ class SeqLoss(nn.Module):
 
     def forward(self, logits, gts, keep_batch=False):
         if not isinstance(logits, LazyLogits):
-            raise NotImplementedError('SeqLoss takes the LazyLogits returned by Decoder.forward; dense logits '
-                                      '(BoW loss, lambda_BoW > 0) are outside the accelerated path')
+            raise NotImplementedError('SeqLoss takes the LazyLogits returned by Decoder.forward (or by '
+                                      'BoW_logits.unsqueeze(1).expand(-1, L, -1)); dense logits are outside the '
+                                      'accelerated path')
         if logits.shape[0] == 0:
             return torch.zeros((), device=gts.device)
         assert logits.shape[:-1] == gts.shape or logits.shape[0] % gts.shape[0] == 0
@@ -182,7 +221,7 @@ class SeqLoss(nn.Module):
             tgt = logits.order.targets(tgt)
         sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad)
         if logits.order is not None:
-            sent = logits.order.back(sent)
+            sent = sent.index_select(0, logits.order.res_idx) if logits.always_restore else logits.order.back(sent)
         if keep_batch:
             return sent
         return sent.sum() / (gts != self.pad).sum().to(sent.dtype)
@@ -543,8 +582,9 @@ class VAE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        logits, dist, z, _, _ = self._run(go, sent_len, bare, _train_order(sent_len))
-        return logits, dist, z, None
+        ro = _train_order(sent_len)
+        logits, dist, z, _, _ = self._run(go, sent_len, bare, ro)
+        return logits, dist, z, LazyBoW(z, self.BoW.weight, self.BoW.bias, _left_sorted(ro))
 
     def _run(self, go, sent_len, bare, ro):
         if ro is not None:
@@ -704,8 +744,9 @@ class VAE_COUPLE(_TextBase):
     def forward(self, go, sent_len=None, bare=None):
         if not self.training:
             raise NotImplementedError()
-        logits, dist, z, logits_c, init, init_c, _ = self._run(go, sent_len, bare, _train_order(sent_len))
-        return logits, dist, z, None, logits_c, init, init_c
+        ro = _train_order(sent_len)
+        logits, dist, z, logits_c, init, init_c, _ = self._run(go, sent_len, bare, ro)
+        return logits, dist, z, LazyBoW(z, self.BoW.weight, self.BoW.bias, _left_sorted(ro)), logits_c, init, init_c
 
     def _run(self, go, sent_len, bare, ro):
         if ro is not None:

@@ -256,8 +256,8 @@ int cvae_couple_forward(const float* init, const float* init_c, int B, int E, in
 int cvae_couple_backward(const float* init, const float* init_c, const float* d, const float* gloss, int B,
                          int E, int Z, int euclid, float* dinit, void* stream);
 
-/* ---- a11: loss assembly (Experiment.py:753-757; CC Experiment.py:405-415): the batch means of n <= 4
- * per-sentence terms (seq, kl, seq_couple, couple) and tot = sum_i coef[i] * mean(term_i), one launch.
+/* ---- a11: loss assembly (Experiment.py:753-757; CC Experiment.py:405-415): the batch means of n <= 6
+ * per-sentence terms (seq, kl, seq_couple, couple; bow of Experiment.py:703-706 when lambda_BoW > 0) and tot = sum_i coef[i] * mean(term_i), one launch.
  * terms: host array of n device pointers [B]; host_coef: n host floats (1, lambda_KL, lambda_seq_couple,
  * lambda_couple).  out[n+1] (device): out[0] = tot, out[1+i] = mean(term_i). */
 int cvae_loss_assemble(int n, int B, const float* const* terms, const float* host_coef, float* out, void* stream);

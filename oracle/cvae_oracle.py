@@ -374,8 +374,27 @@ def train_forward(P, model, cell, batch, noise, cfg):
         out['seq_c'] = seq_c.mean(0)
         out['couple'] = cpl.mean(0)
         tot = tot + out['seq_c'] * cfg['lambda_seq_couple'] + cfg['lambda_couple'] * out['couple']
+    if cfg.get('lambda_bow', 0.0) > 0 and not is_dialog(model):
+        # bag-of-words loss (CV/Experiment.py:703-706 / 737-740): BoW(z) scored against every token of the sentence,
+        # per sentence divided by its length; added to the total only while lambda_KL > 1e-5 (:713-715)
+        bow = bow_xent(P, z, batch['bare'], batch['len'])
+        out['bow_per_sent'] = bow
+        out['bow'] = bow.mean(0)
+        if cfg['lambda_kl'] > 1e-5:
+            tot = tot + cfg['lambda_bow'] * out['bow']
     out['tot'] = tot
     return out
+
+
+def bow_xent(P, z, bare, length, pad=0):
+    """criterionSeq(BoW_logits.unsqueeze(1).expand(-1, L, -1), bare, keep_batch=True) / sent_len
+    (CV/Experiment.py:703-706; BoW = nn.Linear(latent_dim, V), CV/Modules/vae_couple.py:425, 724): for every
+    sentence the sum over its non-pad tokens of -log softmax(BoW(z))[token], divided by its length."""
+    logits = z @ P['BoW.weight'].t() + P['BoW.bias']              # (B, V)
+    logp = torch.log_softmax(logits, dim=1)
+    tok = logp.gather(1, bare)                                    # (B, L)
+    keep = (bare != pad).to(logp.dtype)
+    return -(tok * keep).sum(1) / length.to(logp.dtype)
 
 
 # --------------------------------------------------------------------------- a12

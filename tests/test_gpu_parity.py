@@ -403,10 +403,11 @@ def test_batch_larger_than_maximum_is_refused(dev):
         tr.forward_backward(harness.text_batch(c, range(257), dev))
 
 
-def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sort_rows=False):
+def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sort_rows=False, lambda_bow=0.0):
     from cvae_amd import modules, data, harness
     hp = harness.HParams(model=model, cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'],
-                         lambda_couple=2.0 if model.startswith('cvae') else 0.1, euclidean_dist=euclid)
+                         lambda_couple=2.0 if model.startswith('cvae') else 0.1, euclidean_dist=euclid,
+                         lambda_BoW=lambda_bow)
     tr = harness.Trainer(hp, dev, seed=3)
     sd = tr.model.state_dict(keep_vars=True)
     P = O.tie_aliases({k: v.detach().cpu().clone() for k, v in sd.items()})
@@ -440,7 +441,7 @@ def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sor
         noise['enc_drop'] = drop(cb['bare'].shape[1], B, E)
     replay = {k: (v.unsqueeze(0) if k == 'eps' else v) for k, v in noise.items()}
     cfg = dict(latent_dim=Z, lambda_kl=0.37, lambda_couple=hp.lambda_couple, lambda_seq_couple=1.0,
-               euclidean_dist=euclid)
+               euclidean_dist=euclid, lambda_bow=lambda_bow)
     tr.iter_num = int(0.37 * hp.annealing_step) + hp.annealing_start - 1     # lambda_KL = 0.37 at the next iter
     modules.set_noise_source(modules.ReplayNoise(replay))
     try:
@@ -452,14 +453,27 @@ def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sor
         p_.requires_grad_(True)
     out = O.train_forward(P, model, cell, cb, noise, cfg)
     out['tot'].backward()
-    for k in ('seq', 'kl', 'seq_c', 'couple', 'tot'):
+    for k in ('seq', 'kl', 'seq_c', 'couple', 'bow', 'tot'):
         if k in out:
             assert close(res[k], out[k].detach(), LOSS_TOL), k
+    assert ('bow' in out) == (lambda_bow > 0)
     for k in keys:
         if P[k].grad is None:
             assert float(sd[k].grad.abs().max()) == 0.0, k
         else:
             assert rel(sd[k].grad, P[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize('model', ['vae', 'vae-couple'])
+def test_bow_loss_train_step_vs_oracle(dev, model):
+    """lambda_BoW > 0 (CV/Experiment.py:703-706, 713-715, 737-740; 0 in every shipped config, so no golden vector
+    holds it: parity unpinned, oracle only): the bag-of-words term runs through the fused projection + cross-entropy
+    kernel on z repeated over the sentence's positions (modules.LazyBoW); loss terms and every gradient, the BoW
+    head's included, against the oracle, on rows the product sorts internally (ragged lengths)."""
+    from cvae_amd import data
+    s = dict(V=700, E=40, H=64, Z=16)
+    sents = data.synthetic_sentences(12, s['V'], 2.4, 0.6, 30, seed=21)
+    _train_step_vs_oracle(dev, model, 'lstm', s, sents, [], lambda_bow=0.7)
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
