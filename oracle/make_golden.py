@@ -57,10 +57,17 @@ JOBS = [
      dict(TINY, annealing_start=-10000000, annealing_step=10)),
     ('text_cyc-anneal-vae-couple_lstm_tiny', 'Coupled-VAE', 'ptb', 'cyc-anneal-vae-couple', 'lstm',
      dict(TINY, annealing_start=0, annealing_step=80)),
+    # free bits (CV/Experiment.py:1131-1165).  lambda_fb is substituted (shipped: 6, i.e. 1.5 nats per latent
+    # dimension at Z = 4, which would clamp EVERY dimension of a fresh model) so that clamped and un-clamped
+    # dimensions both occur; lambda_KL = 1 as for beta-vae.  The model restores a pretrained DAE at construction
+    # (Experiment.py:384-410): torch.load of that checkpoint and DAE.load_state_dict are shimmed to no-ops, i.e. the
+    # "pretrained" encoder is the freshly initialised DAE's, which the reference then copies as it always does.
+    ('text_surprising-fix_gru_tiny', 'Coupled-VAE', 'ptb', 'surprising-fix', 'gru',
+     dict(TINY, annealing_start=-10000000, annealing_step=10, lambda_fb=0.3)),
     ('text_dae_gru_tiny', 'Coupled-VAE', 'ptb', 'dae', 'gru', TINY),
     ('text_lm_gru_tiny', 'Coupled-VAE', 'ptb', 'lm', 'gru', TINY),
 ]
-BASE_MODEL = {'beta-vae': 'vae', 'cyc-anneal-vae': 'vae', 'cyc-anneal-vae-couple': 'vae-couple'}
+BASE_MODEL = {'beta-vae': 'vae', 'cyc-anneal-vae': 'vae', 'cyc-anneal-vae-couple': 'vae-couple', 'surprising-fix': 'vae'}
 
 NOISE_ORDER = {
     # training-forward draw order (SURVEY 8a "RNG draw order")
@@ -129,6 +136,8 @@ def _patched_config_source(tree, dataset, model, cell, shp):
     if 'annealing_start' in shp:
         src = re.sub(r'self\.annealing_start = \d+', 'self.annealing_start = %d' % shp['annealing_start'], src)
         src = re.sub(r'self\.annealing_step = \d+', 'self.annealing_step = %d' % shp['annealing_step'], src)
+    if 'lambda_fb' in shp:
+        src = re.sub(r'self\.lambda_fb = \d+', 'self.lambda_fb = %r' % shp['lambda_fb'], src)
     return src
 
 
@@ -235,8 +244,15 @@ def child(name, tree, dataset, model, cell, shp, out_path):
 
     E.euclidean = rec_euc
 
+    if model.startswith('surprising-fix'):
+        # no pretrained DAE checkpoint exists here: the freshly initialised DAE stands in for it (see JOBS)
+        _orig_load = torch.load
+        torch.load = lambda *a, **k: {}
+        E.DAE.load_state_dict = lambda self, sd, strict=True: None
     with contextlib.redirect_stdout(io.StringIO()):
         exp = E.Experiment()
+    if model.startswith('surprising-fix'):
+        torch.load = _orig_load
     ae = exp.AutoEncoder
     keys_all = list(ae.state_dict().keys())
     out = {}
@@ -249,6 +265,7 @@ def child(name, tree, dataset, model, cell, shp, out_path):
                 annealing_start=getattr(E.config, 'annealing_start', 0),
                 annealing_step=getattr(E.config, 'annealing_step', 1),
                 beta=getattr(E.config, 'beta', 1.0), cyc_M=getattr(E.config, 'M', 0), cyc_R=getattr(E.config, 'R', 0.0),
+                lambda_fb=float(getattr(E.config, 'lambda_fb', 0.0)),
                 dropout=E.config.dropout, clip_norm=E.config.clip_norm, lr=E.config.gen_lr,
                 torch_version=torch.__version__)
 

@@ -54,4 +54,13 @@ class Golden(object):
         m = self.meta
         return dict(latent_dim=m['Z'], lambda_kl=lambda_kl, lambda_couple=m['lambda_couple'],
                     lambda_seq_couple=m['lambda_seq_couple'], euclidean_dist=m['euclidean_dist'],
-                    lr=m['lr'], clip_norm=m['clip_norm'])
+                    lr=m['lr'], clip_norm=m['clip_norm'], lambda_fb=m.get('lambda_fb', 0.0))
+
+    def kl_per_sentence(self, prefix):
+        """The KL term of every sentence as the recorded model's training loop forms it from the recorded
+        kl_divergence(q, p) elements: their sum, or for surprising-fix* the sum of the elements floored at
+        lambda_fb / Z (free bits, CV/Experiment.py:1141-1142)."""
+        k = self.t(prefix + 'kl_elem')
+        if self.meta['model'].startswith('surprising-fix'):
+            k = torch.clamp(k, min=self.meta['lambda_fb'] / self.meta['Z'])
+        return k.sum(1)

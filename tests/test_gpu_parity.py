@@ -42,7 +42,8 @@ def make_trainer(g, dev, prefix='init/'):
                          annealing_start=m['annealing_start'], annealing_step=m['annealing_step'],
                          lambda_couple=m['lambda_couple'], lambda_seq_couple=m['lambda_seq_couple'],
                          euclidean_dist=m['euclidean_dist'], max_len=m['max_len'], batch_size=m['B'],
-                         beta=m.get('beta', 0.8), cyc_M=m.get('cyc_M') or 4, cyc_R=m.get('cyc_R') or 0.5)
+                         beta=m.get('beta', 0.8), cyc_M=m.get('cyc_M') or 4, cyc_R=m.get('cyc_R') or 0.5,
+                         lambda_fb=m.get('lambda_fb') or 6.0)
     model = harness.build_model(hp, 'cpu', seed=0)
     model.load_state_dict({k: g.t(prefix + k) for k in m['state_keys']}, strict=True)
     return harness.Trainer(hp, dev, model=model.to(dev))
@@ -64,7 +65,7 @@ def test_train_steps_match_reference(dev, name):
             assert abs(res['lambda_kl'] - float(g.np(p + 'lambda_kl'))) < 1e-12   # schedule of the variant
             assert close(res['seq'], g.t(p + 'seq_per_sent').mean(), LOSS_TOL)
             if m['model'] not in ('dae', 'lm'):
-                assert close(res['kl'], g.t(p + 'kl_elem').sum(1).mean(), LOSS_TOL)
+                assert close(res['kl'], g.kl_per_sentence(p).mean(), LOSS_TOL)
             if O.is_couple(m['model']):
                 assert close(res['seq_c'], g.t(p + 'seq_c_per_sent').mean(), LOSS_TOL)
             assert close(res['tot'], g.np(p + 'tot'), LOSS_TOL)
