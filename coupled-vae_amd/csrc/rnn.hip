@@ -327,8 +327,21 @@ static int rnn_backward_stream(const RnnBwd* arr, int ns, hipStream_t s) {
   }
   const int ks = stream_linear_ksplit(ns, H, G * H);
   void* pbuf = nullptr;
-  CVAE_TRY(lib_scratch(LS_STREAM_PARTS, s, (size_t)ns * ks * RH * sizeof(float), &pbuf));
+  const size_t parts_bytes = ((size_t)ns * ks * RH * sizeof(float) + 15) / 16 * 16;
+  CVAE_TRY(lib_scratch(LS_STREAM_PARTS, s, parts_bytes + (size_t)ns * 64 * sizeof(int64_t), &pbuf));
   float* parts = static_cast<float*>(pbuf);
+  // unpacked sequences (decoders) that come without a row bound: rows past their last non-zero output gradient
+  // stay exactly zero for the rest of the backward pass (as launch_rnn_backward_persist does)
+  const int64_t* za[SKINNY_MAX_BATCH];
+  for (int q = 0; q < ns; ++q) {
+    const RnnBwd& a = arr[q];
+    za[q] = a.zero_after ? a.zero_after : a.lengths;
+    if (!za[q] && a.dhs && !a.dh_last && !a.dc_last) {
+      int64_t* zbuf = reinterpret_cast<int64_t*>(static_cast<char*>(pbuf) + parts_bytes) + (size_t)q * 64;
+      CVAE_TRY(launch_last_nonzero_step(T, R, H, a.dhs, zbuf, s));
+      za[q] = zbuf;
+    }
+  }
   const dim3 cgrid(cdiv(RH, 256), ns);
   SkinnyArgs kk[SKINNY_MAX_BATCH];
   for (int i = T - 1; i >= -1; --i) {
@@ -352,6 +365,9 @@ static int rnn_backward_stream(const RnnBwd* arr, int ns, hipStream_t s) {
       k = SkinnyArgs{};
       k.A = (a.dgh ? a.dgh : a.dgx) + goff; k.lda = (long)G * H;
       k.M = R; k.N = H; k.K = G * H; k.ngroups = 4;
+      // rows whose dG_t is exactly zero (a padded step of a packed sequence, a decoder row past its last target)
+      // are left out of the product: their partial rows are written as zeros
+      k.lengths = za[q]; k.t = t;
     }
     const float* pin = (i == T - 1) ? nullptr : parts;
     {

@@ -424,8 +424,18 @@ __global__ __launch_bounds__(64 * ST_NW) void skinny_stream_kernel(SkinnyBatch b
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Row tiles that hold no live row contribute nothing the epilogue uses (forward: a dead row only carries its
+  // state; partial-product form: a dead row's A is exactly zero and so is its output, written below): neither
+  // loaded nor multiplied.  bound = 1 + the highest row with t < lengths[row] (rows sorted by length: the live count).
+  int mt_live = MT;
+  if (p.lengths) {
+    const bool lv = lane < p.M && (int64_t)p.t < p.lengths[lane];
+    const unsigned long long mask = __ballot(lv);
+    const int bound = mask ? 64 - __clzll(mask) : 0;
+    mt_live = (bound + 15) >> 4;
+  }
   const int kb0 = blockIdx.y * kb_split;
-  const int kb1 = (kb0 + kb_split < nkb) ? kb0 + kb_split : nkb;
+  const int kb1 = (kb0 + kb_split < nkb && mt_live > 0) ? kb0 + kb_split : (mt_live > 0 ? nkb : kb0);
   const bf16x8* bimg = reinterpret_cast<const bf16x8*>(imgs.p[blockIdx.z]) + (long)blockIdx.x * nkb * (NG * 128) + lane;
   const float* Ap[MT];
 #pragma unroll
@@ -445,8 +455,10 @@ __global__ __launch_bounds__(64 * ST_NW) void skinny_stream_kernel(SkinnyBatch b
       bl[set][g] = bsrc[g * 128 + 64];                                                     \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                       \
-      ar[set][i][0] = *reinterpret_cast<const f32x4*>(Ap[i] + (long)(kb) * 32);            \
-      ar[set][i][1] = *reinterpret_cast<const f32x4*>(Ap[i] + (long)(kb) * 32 + 4);        \
+      if (i < mt_live) {                                                                   \
+        ar[set][i][0] = *reinterpret_cast<const f32x4*>(Ap[i] + (long)(kb) * 32);          \
+        ar[set][i][1] = *reinterpret_cast<const f32x4*>(Ap[i] + (long)(kb) * 32 + 4);      \
+      }                                                                                    \
     }                                                                                      \
   } while (0)
 
@@ -458,26 +470,21 @@ __global__ __launch_bounds__(64 * ST_NW) void skinny_stream_kernel(SkinnyBatch b
       const int kc = kb + ST_NW * u;
       if (kc < kb1) {
         if (kc + ST_NW < kb1) ST_LOAD(u ^ 1, kc + ST_NW);
-        bf16x8 ah[MT], al[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const f32x4 a0 = ar[u][i][0], a1 = ar[u][i][1];
-          const f32x8 v = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-          ah[i] = __builtin_convertvector(v, bf16x8);
-          al[i] = __builtin_convertvector(v - __builtin_convertvector(ah[i], f32x8), bf16x8);
+          if (i < mt_live) {                                 // wave-uniform
+            const f32x4 a0 = ar[u][i][0], a1 = ar[u][i][1];
+            const f32x8 v = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const bf16x8 ah = __builtin_convertvector(v, bf16x8);
+            const bf16x8 al = __builtin_convertvector(v - __builtin_convertvector(ah, f32x8), bf16x8);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[u][g], acc[i][g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[u][g], acc[i][g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[u][g], acc[i][g], 0, 0, 0);
+          }
         }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[u][g], acc[i][g], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[u][g], acc[i][g], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int g = 0; g < NG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[u][g], acc[i][g], 0, 0, 0);
       }
     }
   }
