@@ -211,6 +211,130 @@ __device__ __forceinline__ void gemm_nt_body(const TiledArgs& p) {
   }
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(TiledArgs p) { gemm_nt_body(p); }
+
+// The same product on the bf16 matrix pipe, error-compensated ("bf16x3": both operands split into bf16 hi + lo while
+// they are staged, hi.lo + lo.hi + hi.hi per 16-deep K block, fp32 accumulation; the forward products' form, see
+// ce_fast.hip / rnn_large.hip, whose main loop this is).  K chunk 32, LDS rows of four 16-byte slots XOR-swizzled with
+// (row >> 2) & 3, two register sets (chunk kt+2 is fetched while chunk kt is multiplied), 64 KB of LDS.  K a multiple
+// of 8: the slots of a last partial chunk are zero-filled.
+typedef __bf16 nt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float nt_f32x8 __attribute__((ext_vector_type(8)));
+constexpr int NTB_BK = 32;
+__device__ __forceinline__ void gemm_nt_bf3_body(const TiledArgs& p) {
+  constexpr int A_SL = 128 * 4, B_SL = 128 * 4, BUF_SL = 2 * A_SL + 2 * B_SL;   // slots: [A hi][A lo][B hi][B lo]
+  extern __shared__ __attribute__((aligned(16))) float nt_smem[];
+  nt_bf16x8* sm = reinterpret_cast<nt_bf16x8*>(nt_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const float* __restrict__ gA = p.A;
+  const float* __restrict__ gB = p.B;
+  long oa[2], ob[2];
+  int slot[2], ksl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, r = idx >> 2, sl = idx & 3;       // task: row r, 8 k from 8*sl
+    oa[i] = (long)min(m0 + r, p.M - 1) * p.lda + 8 * sl;
+    ob[i] = (long)min(n0 + r, p.N - 1) * p.ldb + 8 * sl;
+    slot[i] = r * 4 + (sl ^ ((r >> 2) & 3));
+    ksl[i] = 8 * sl;
+  }
+  int kload = 0;
+  f32x4 ra[2][2][2], rb[2][2][2];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#define NTB_LOAD(set)                                                                            \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+      const bool in = kload + ksl[i] < p.K;                                                      \
+      ra[set][i][0] = in ? *reinterpret_cast<const f32x4*>(gA + oa[i] + kload) : z4;             \
+      ra[set][i][1] = in ? *reinterpret_cast<const f32x4*>(gA + oa[i] + kload + 4) : z4;         \
+      rb[set][i][0] = in ? *reinterpret_cast<const f32x4*>(gB + ob[i] + kload) : z4;             \
+      rb[set][i][1] = in ? *reinterpret_cast<const f32x4*>(gB + ob[i] + kload + 4) : z4;         \
+    }                                                                                            \
+    kload += NTB_BK;                                                                             \
+  } while (0)
+#define NTB_SPLIT(x0, x1, hi, lo)                                                                \
+  do {                                                                                           \
+    const nt_f32x8 v_ = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                \
+    hi = __builtin_convertvector(v_, nt_bf16x8);                                                 \
+    lo = __builtin_convertvector(v_ - __builtin_convertvector(hi, nt_f32x8), nt_bf16x8);         \
+  } while (0)
+#define NTB_STORE(set, buf)                                                                      \
+  do {                                                                                           \
+    nt_bf16x8* base = sm + (buf) * BUF_SL;                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+      nt_bf16x8 hi, lo;                                                                          \
+      NTB_SPLIT(ra[set][i][0], ra[set][i][1], hi, lo);                                           \
+      base[slot[i]] = hi;                                                                        \
+      base[A_SL + slot[i]] = lo;                                                                 \
+      NTB_SPLIT(rb[set][i][0], rb[set][i][1], hi, lo);                                           \
+      base[2 * A_SL + slot[i]] = hi;                                                             \
+      base[2 * A_SL + B_SL + slot[i]] = lo;                                                      \
+    }                                                                                            \
+  } while (0)
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  const int arow = wave * 32 + l31, sw = (l31 >> 2) & 3;
+  const int nk = (p.K + NTB_BK - 1) / NTB_BK;
+  NTB_LOAD(0);
+  NTB_STORE(0, 0);
+  if (nk > 1) NTB_LOAD(1);
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nk) {
+        if (kt + 2 < nk) NTB_LOAD(u);
+        const nt_bf16x8* base = sm + u * BUF_SL;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int sl = (2 * kb + lhi) ^ sw;
+          const nt_bf16x8 ah = base[arow * 4 + sl], al = base[A_SL + arow * 4 + sl];
+          nt_bf16x8 bh[4], bl[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bh[g] = base[2 * A_SL + (g * 32 + l31) * 4 + sl];
+            bl[g] = base[2 * A_SL + B_SL + (g * 32 + l31) * 4 + sl];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
+        }
+        if (kt + 1 < nk) NTB_STORE(u ^ 1, u ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+#undef NTB_LOAD
+#undef NTB_SPLIT
+#undef NTB_STORE
+  // acc[g][r] = C[m0 + 32*wave + (r&3) + 8*(r>>2) + 4*lhi][n0 + 32*g + l31]
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = n0 + 32 * g + l31;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (m < p.M) {
+        float* c = p.C + (long)m * p.ldc + n;
+        float v = apply_act(acc[g][r] + bv, p.act);
+        if (p.beta) v += *c;
+        *c = v;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf3_kernel(TiledArgs p) { gemm_nt_bf3_body(p); }
+constexpr size_t NTB_LDS = (size_t)2 * (4 * 128 * 4) * 16;      // 64 KB
 static bool gemm_nt_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("CVAE_GEMM_NT"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -220,6 +344,11 @@ static bool gemm_nt_enabled() {
 static bool gemm_nt_ok(const GemmDesc& d) {
   return gemm_nt_enabled() && !d.transA && d.transB && d.K >= NT_BK && d.K % NT_BK == 0 && d.act != ACT_CEGRAD &&
          aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0;
+}
+// the split-bf16 form: on by default (cvae_split_bf16), K a multiple of 8
+static bool gemm_nt_bf3_ok(const GemmDesc& d) {
+  return gemm_nt_enabled() && split_bf16_enabled() && !d.transA && d.transB && d.K >= 32 && d.K % 8 == 0 &&
+         d.act != ACT_CEGRAD && aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0;
 }
 
 // Batch of products with one B: blockIdx.z = batch; A and C advance by a stride, the row count of
@@ -240,6 +369,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_batched_kernel(TiledArgs p, Ti
   p.A += (long)blockIdx.z * b.sA;
   p.C += (long)blockIdx.z * b.sC;
   gemm_nt_body(p);
+}
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf3_batched_kernel(TiledArgs p, TiledBatch b) {
+  p.M = b.m[blockIdx.z];
+  if ((int)blockIdx.y * 128 >= p.M) return;
+  p.A += (long)blockIdx.z * b.sA;
+  p.C += (long)blockIdx.z * b.sC;
+  gemm_nt_bf3_body(p);
+}
+static int gemm_nt_bf3_attr() {
+  static bool done = false;
+  if (!done) {
+    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "gemm_nt_bf3 LDS attribute"));
+    CVAE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf3_batched_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "gemm_nt_bf3 LDS attribute"));
+    done = true;
+  }
+  return 0;
 }
 
 static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
@@ -265,9 +412,12 @@ static int launch_tiled_batched(const GemmDesc& d, hipStream_t s) {
   if (mmax == 0) return 0;
   constexpr int BM = 128, BN = 128;
   dim3 grid(cdiv(d.N, BN), cdiv(mmax, BM), d.nbatch);
-  const bool nt = gemm_nt_ok(d) && d.batchA % 4 == 0;
+  const bool nt = (gemm_nt_ok(d) || gemm_nt_bf3_ok(d)) && d.batchA % 4 == 0;
   ProfScope prof(nt ? PK_GEMM_NT : PK_GEMM_TILED, s, 2.0 * rows * d.N * d.K);
-  if (nt) hipLaunchKernelGGL(gemm_nt_batched_kernel, grid, dim3(256), 0, s, a, b);
+  if (nt && gemm_nt_bf3_ok(d)) {
+    CVAE_TRY(gemm_nt_bf3_attr());
+    hipLaunchKernelGGL(gemm_nt_bf3_batched_kernel, grid, dim3(256), NTB_LDS, s, a, b);
+  } else if (nt) hipLaunchKernelGGL(gemm_nt_batched_kernel, grid, dim3(256), 0, s, a, b);
   else if (d.transB) hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, b);
   else hipLaunchKernelGGL((gemm_tiled_batched_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, a, b);
   CVAE_LAUNCH_CHECK("gemm_tiled_batched");
@@ -304,10 +454,15 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
     }
   }
   dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), ksplit);
-  const bool nt = BM == 128 && BN == 128 && ksplit == 1 && gemm_nt_ok(d);
+  const bool nt = BM == 128 && BN == 128 && ksplit == 1 && (gemm_nt_ok(d) || gemm_nt_bf3_ok(d));
   ProfScope prof(nt ? PK_GEMM_NT : PK_GEMM_TILED, s, 2.0 * d.M * d.N * d.K);
   if (nt) {
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+    if (gemm_nt_bf3_ok(d)) {
+      CVAE_TRY(gemm_nt_bf3_attr());
+      hipLaunchKernelGGL(gemm_nt_bf3_kernel, grid, dim3(256), NTB_LDS, s, a);
+    } else {
+      hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+    }
     CVAE_LAUNCH_CHECK("gemm_nt");
     return 0;
   }

@@ -71,7 +71,10 @@ def test_gemm(dev, case):
     M, N, K, tA, tB, bias, act, beta = case
     A = rnd(*((K, M) if tA else (M, K)), dev=dev, seed=1)
     B = rnd(*((N, K) if tB else (K, N)), dev=dev, seed=2)
-    if act == 3:
+    if act in (1, 3):
+        # pre-activations of the size the model has (|x| of a few units): the split-bf16 x W^T product is accurate to
+        # ~5e-6 of the pre-activation's magnitude (2^-17 per product), which a tanh over |x| ~ 50 would turn into
+        # an absolute 3e-4 around its zero crossing
         A = A * 0.1
     b = rnd(N, dev=dev, seed=3) if bias else None
     C0 = rnd(M, N, dev=dev, seed=4)
@@ -84,7 +87,10 @@ def test_gemm(dev, case):
     ref = {0: lambda x: x, 1: torch.tanh, 2: torch.relu, 3: torch.exp}[act](ref)
     if beta:
         ref = ref + C0.double()
-    assert rel(out, ref) < 2e-5, case
+    # x W^T products run as split-bf16 (bf16x3) by default: 2^-17 per product, i.e. a few 1e-6 of the
+    # pre-activation's magnitude (fp32-input MFMA: ~1e-7); every other form is fp32-input or bf16x6
+    tol = 6e-5 if (tB and not tA) else 2e-5
+    assert rel(out, ref) < tol, case
 
 
 def test_gemm_strided_operands(dev):
