@@ -38,7 +38,8 @@ PEAK_HBM_GBS = 8000.0
 # kernels whose product runs as error-compensated split-bf16: operands split into two bf16 terms and three bf16
 # MFMA passes per fp32 product (bf16x3: forward products), or three terms and six passes (bf16x6: the gradient
 # products of gemm_wide).  Their algorithmic fp32 FLOP/s are priced against the bf16 peak / passes
-SPLIT_BF16_KERNELS = {'ce_core_kernel': 3, 'rnn_large_step_kernel': 3, 'gemm_wide_kernel': 6}
+SPLIT_BF16_KERNELS = {'ce_core_kernel': 3, 'rnn_large_step_kernel': 3, 'gemm_wide_kernel': 6, 'gemm_nt_kernel': 3,
+                      'rnn_fwd_persist_kernel': 3, 'rnn_bwd_persist_kernel': 6}
 SPLIT_BF16 = True
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
            3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
@@ -436,7 +437,8 @@ def main():
             'dtype_note': ('fp32 storage, accumulation and results; the hidden x vocab product and the many-row gate product of '
                            'IW evaluation run as error-compensated split-bf16 (3 bf16 MFMA passes per fp32 product; error vs fp64 '
                            'equal to the fp32-input MFMA kernels: tests/test_gpu_kernels.py::test_projce_bf16x3_error), the '
-                           'sequence-wide gradient products with a three-term split (6 passes; scripts/grad_error_modes.py)'
+                           'sequence-wide gradient products and the backward recurrence with a three-term split (6 passes; '
+                           'scripts/grad_error_modes.py), x W^T projections and the forward recurrence with the two-term split'
                            if SPLIT_BF16 else 'fp32-input MFMA everywhere (CVAE_SPLIT_BF16=0)'), 'data': 'synthetic',
             'config': {'workload': '%s-shape Coupled-VAE (vae-couple, %s): V=%d E=%d H=%d Z=%d, batch %d per GPU, '
                                    'lengths lognormal(%.1f,%.2f) cap %d, rows in corpus (shuffled) order; train step + IW-NLL K=%d'
