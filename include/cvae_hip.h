@@ -304,7 +304,8 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
  * hidden x vocab product of cvae_projce_* (E <= 200, E % 8 == 0, 16-byte rows) and the many-row recurrent gate
  * product of the IW-evaluation decoder (R > 256) run as error-compensated split-bf16 ("bf16x3") by default: every
  * fp32 operand = hi + lo in bf16, product = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation -- relative error ~2^-16 per product.  Measured against fp64 at E = 200, V = 20000: per-sentence loss
+ * accumulation -- relative error ~2^-17 per product, i.e. one output is accurate to ~5e-6 of its magnitude (fp32-input
+ * MFMA: ~1e-7); the x W^T projections (K a multiple of 8) and the forward recurrence use the same form.  Measured against fp64 at E = 200, V = 20000: per-sentence loss
  * 2.0e-7 relative (fp32-input MFMA kernel: 1.7e-7), gradients 9.8e-7 for both
  * (tests/test_gpu_kernels.py::test_projce_bf16x3_error).  The long-K gradient products (dX = P.W, [dW|db] = P^T.[X|1],
  * the recurrent layers' weight gradients; 16-byte aligned operands) use a THREE-term split and the six leading
