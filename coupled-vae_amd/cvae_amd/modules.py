@@ -42,6 +42,12 @@ class NoiseSource(object):
     def normal(self, shape, device, name):
         return torch.empty(shape, dtype=torch.float32, device=device).normal_()
 
+    def normal_chunks(self, n_chunks, shape, device, name):
+        """n_chunks consecutive draws of `shape`, concatenated along dim 0 (the reference draws the importance
+        samples' eps in K/2 chunks of (2,B,Z)).  Here: ONE launch for the same number of iid normals (K/2 launches of
+        3 us each were 1.5 % of an evaluation batch); a replay hands back the recorded chunks one by one."""
+        return torch.empty((n_chunks * shape[0],) + tuple(shape[1:]), dtype=torch.float32, device=device).normal_()
+
 
 class ReplayNoise(NoiseSource):
     """Replays named tensors (golden fixtures): dict name -> tensor or list of tensors.  The recorded tensors are
@@ -72,6 +78,9 @@ class ReplayNoise(NoiseSource):
         if t is None:   # draws whose value is discarded by the model (e.g. eps_couple)
             return torch.zeros(shape, dtype=torch.float32, device=device)
         return t
+
+    def normal_chunks(self, n_chunks, shape, device, name):
+        return torch.cat([self.normal(shape, device, name) for _ in range(n_chunks)], 0)
 
 
 _noise = NoiseSource()
@@ -419,7 +428,7 @@ def _iw_nll(decoder, to_init_seq, go, eos, mu, sigma, mu_p, sigma_p, post_repr, 
     B, T = go.shape
     Z = mu.shape[1]
     dev = go.device
-    eps = torch.cat([_noise.normal((n_chunk, B, Z), dev, 'iw_eps') for _ in range(n_sample // n_chunk)], 0)
+    eps = _noise.normal_chunks(n_sample // n_chunk, (n_chunk, B, Z), dev, 'iw_eps')
     sharded = settings.shard_samples and dist_utils.world() > 1
     if sharded:
         dist_utils.broadcast_(eps)                                      # one eps sequence for every rank
@@ -549,8 +558,7 @@ class _TextBase(nn.Module):
             n_chunk = settings.n_sample_chunk
             assert n_sample % n_chunk == 0
             B, Z = mu.shape
-            eps = torch.cat([_noise.normal((n_chunk, B, Z), mu.device, 'mi_eps')
-                             for _ in range(n_sample // n_chunk)], 0)
+            eps = _noise.normal_chunks(n_sample // n_chunk, (n_chunk, B, Z), mu.device, 'mi_eps')
             z = ops.rsample_n(mu, sigma, eps)
             return ops.mi(z, mu, sigma), z.transpose(0, 1)
 
