@@ -352,11 +352,24 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 #define GW_DEEP_RING 0      // 1: two-chunk-ahead register ring (measured: spills at 2 waves per SIMD)
 #endif
 
+// GW_EXP_* : timing-only diagnostic builds (scripts/build_variant.sh); results are wrong with any of them set
+#ifndef GW_EXP_NOSPLIT
+#define GW_EXP_NOSPLIT 0
+#endif
+#ifndef GW_EXP_NOMFMA
+#define GW_EXP_NOMFMA 0
+#endif
 __device__ __forceinline__ void gw_split(const f32x8 v, bf16x8 (&t)[3]) {
+#if GW_EXP_NOSPLIT
+  union { f32x8 f; bf16x8 h[2]; } u;
+  u.f = v;
+  t[0] = u.h[0]; t[1] = u.h[1]; t[2] = u.h[0];
+#else
   t[0] = __builtin_convertvector(v, bf16x8);
   const f32x8 r1 = v - __builtin_convertvector(t[0], f32x8);
   t[1] = __builtin_convertvector(r1, bf16x8);
   t[2] = __builtin_convertvector(r1 - __builtin_convertvector(t[1], f32x8), bf16x8);
+#endif
 }
 
 template <bool AKC, int NF>
@@ -500,12 +513,16 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
       for (int j = 0; j < NF; ++j) {
         const int bs = 3 * A_SL + (32 * j + l31) * 2 + b_sw;
         const bf16x8 bh = base[bs], bm = base[B_SL + bs], bl = base[2 * B_SL + bs];
+#if GW_EXP_NOMFMA
+        acc[j][0] += (float)am[0] * (float)bm[0] + (float)ah[1] * (float)bl[1] + (float)al[2] * (float)bh[2];
+#else
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);      // smallest terms first
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+#endif
       }
     };
 
