@@ -359,6 +359,12 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 #ifndef GW_EXP_NOMFMA
 #define GW_EXP_NOMFMA 0
 #endif
+#ifndef GW_EXP_NOLOAD
+#define GW_EXP_NOLOAD 0
+#endif
+#ifndef GW_EXP_NOLDS
+#define GW_EXP_NOLDS 0
+#endif
 __device__ __forceinline__ void gw_split(const f32x8 v, bf16x8 (&t)[3]) {
 #if GW_EXP_NOSPLIT
   union { f32x8 f; bf16x8 h[2]; } u;
@@ -529,14 +535,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
     // interior chunks (every load a whole in-bounds float4: full k range, full column groups, and for a k-major A
     // a full row tile) take a branch-free path on per-task base pointers; k-major operands that go through the
     // row list fetch their 8 row indices per chunk with two 16-byte loads
-    const bool fast_item = ncols == tw && (AKC || m0 + G2_BM <= Mlim);
+    // (A k-major row tile that sticks out past Mlim: its column groups are clamped to the last whole one -- the
+    // duplicated columns only feed accumulator rows that are never stored.  Left on the guarded path, the items of
+    // the LAST row tile ran several times longer than every other item and set the launch's duration: the
+    // [dW | db] product of ToVocab, 157 row tiles, 353 -> see DESIGN 4.)
+    const bool fast_item = ncols == tw && (AKC || m0 + G2_BM <= Mlim || Mlim >= 4);
+    // the one column group that straddles Mlim (Mlim not a multiple of 4) is fetched element by element
+    const int a_m = m0 + 4 * a_cg;
+    const bool a_straddle = !AKC && has_a && a_m < Mlim && a_m + 4 > Mlim;
     const float* fa;
     const float* fb = p.B + n0 + 4 * b_cg;
     if (AKC) {
       const int mm = min(m0 + a_row, Mlim - 1);
       fa = p.A + (p.a_ind ? (long)p.rows[p.r0 + mm] : (long)mm) * p.lda + 8 * a_kh;
     } else {
-      fa = p.A + m0 + 4 * a_cg;
+      fa = p.A + (a_m + 4 <= Mlim ? a_m : (a_straddle ? a_m : ((Mlim - 4) & ~3)));
     }
     const bool rows16 = ((p.r0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.rows) & 15) == 0);   // 16-byte aligned slices of 4 indices
     auto fast_load = [&](int k0, float4 (&ra)[AKC ? 2 : 1], float4 (&rt)[8]) {
@@ -554,8 +567,16 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) ri[kk] = p.rows[p.r0 + kb + kk];
           }
+          if (a_straddle) {
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)ri[kk] * p.lda);
+            for (int kk = 0; kk < 8; ++kk) rt[kk] = ld4g(fa + (long)ri[kk] * p.lda, a_m, Mlim, 0);
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)ri[kk] * p.lda);
+          }
+        } else if (a_straddle) {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) rt[kk] = ld4g(fa + (long)(kb + kk) * p.lda, a_m, Mlim, 0);
         } else {
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)(kb + kk) * p.lda);
@@ -583,6 +604,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
     const int nk = (kend - kbeg + G2_BK - 1) / G2_BK;
     const int nfast = fast_item ? (kend - kbeg) / G2_BK : 0;   // interior chunks form a prefix
     auto fetch = [&](int c, float4 (&ra)[AKC ? 2 : 1], float4 (&rt)[8]) {      // chunk c of the item -> a register set
+#if GW_EXP_NOLOAD
+      if (c > 0 && c < nfast) return;
+#endif
       if (c < nfast) fast_load(kbeg + c * G2_BK, ra, rt);
       else if (c < nk) load(kbeg + c * G2_BK, ra, rt);
     };
@@ -611,7 +635,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
       for (int kt = 0; kt < nk; ++kt) {
         fetch(kt + 1, ra_[0], rt_[0]);
         compute(kt & 1);
+#if GW_EXP_NOLDS
+        if (kt + 1 < nk && kt < 1) store((kt & 1) ^ 1, ra_[0], rt_[0]);
+#else
         if (kt + 1 < nk) store((kt & 1) ^ 1, ra_[0], rt_[0]);
+#endif
         __syncthreads();
       }
     }
