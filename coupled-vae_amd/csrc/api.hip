@@ -757,7 +757,7 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   float* dgx[SKINNY_MAX_BATCH]; float* dgh[SKINNY_MAX_BATCH]; float* dX[SKINNY_MAX_BATCH];
   LiveRows live_w[SKINNY_MAX_BATCH], live_r[SKINNY_MAX_BATCH];
   const LiveRows* lrw[SKINNY_MAX_BATCH]; const LiveRows* lrr[SKINNY_MAX_BATCH];
-  const bool use_live = live_rows_enabled() && (long)T * B >= 1024 && B <= 32;
+  const bool use_live = live_rows_enabled() && (long)T * B >= 1024 && B <= SKINNY_MAX_ROWS;
   const long per_dec = (4L * B + 16 + (long)T * B + (long)T1 * B + 3) / 4 * 4;     // ints per decoder
   int* rows_buf = nullptr;
   if (use_live) {
