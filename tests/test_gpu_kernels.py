@@ -53,6 +53,8 @@ GEMM_CASES = [
     (6432, 200, 1024, 0, 0, 0, 0, 0),      # dX = dG W_ih
     (2048, 512, 3000, 1, 0, 0, 0, 0),      # decoder dW_hh: four 128-column tiles
     (200, 512, 3000, 1, 0, 0, 0, 1),       # dW_c accumulate
+    (1334, 200, 1500, 1, 0, 0, 0, 0),      # k-major A, last row tile partial (54 rows) and M % 4 == 2: clamped groups + a straddling one
+    (20004, 200, 700, 1, 0, 0, 0, 1),      # ToVocab-like: 157 row tiles, the last one 36 rows wide, accumulate
     # x W^T with >= 192 output tiles (128x128 tiles): K tails, ragged edges, epilogues
     (6400, 2048, 400, 0, 1, 1, 0, 0),      # decoder input projection: K tail of 16
     (2100, 1540, 200, 0, 1, 1, 1, 0),      # ragged M / N, bias + tanh, K tail of 8
