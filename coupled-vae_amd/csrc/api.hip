@@ -148,25 +148,33 @@ static int lib_rows(long ints, int** out, hipStream_t s) {
 
 // db != null: also db[N] = column sums of dy (the bias gradient), see GemmDesc::colsum_out
 // lr != null: only the listed rows of dy / x are visited (the others are exactly zero in dy)
-static int grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
-                       int beta, hipStream_t s, float* db = nullptr, const LiveRows* lr = nullptr) {
+static GemmDesc desc_grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
+                                 int beta, float* db = nullptr, const LiveRows* lr = nullptr) {
   GemmDesc d = {};
   d.transA = 1; d.transB = 0; d.M = N; d.N = K; d.K = M;
   d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dW; d.ldc = K; d.beta = beta; d.colsum_out = db;
   if (lr) { d.rows = lr->rows; d.nlive = lr->n; d.bound_dim = 2; }
-  return launch_gemm(d, s);
+  return d;
+}
+static int grad_weight(const float* dy, long lddy, const float* x, long ldx, int M, int N, int K, float* dW,
+                       int beta, hipStream_t s, float* db = nullptr, const LiveRows* lr = nullptr) {
+  return launch_gemm(desc_grad_weight(dy, lddy, x, ldx, M, N, K, dW, beta, db, lr), s);
 }
 
 // dx[M,K] = dy[M,N] . W[N,K]
 // lr != null: only the listed rows of dy are visited and only those rows of dx written: the caller has
 // zeroed dx (beta == 0) or dx already holds the term to add to (beta == 1)
-static int grad_input(const float* dy, long lddy, const float* W, long ldw, int M, int N, int K, float* dx,
-                      long lddx, int beta, hipStream_t s, const LiveRows* lr = nullptr) {
+static GemmDesc desc_grad_input(const float* dy, long lddy, const float* W, long ldw, int M, int N, int K, float* dx,
+                                long lddx, int beta, const LiveRows* lr = nullptr) {
   GemmDesc d = {};
   d.transA = 0; d.transB = 0; d.M = M; d.N = K; d.K = N;
   d.A = dy; d.lda = lddy; d.B = W; d.ldb = ldw; d.C = dx; d.ldc = lddx; d.beta = beta;
   if (lr) { d.rows = lr->rows; d.nlive = lr->n; d.bound_dim = 1; }
-  return launch_gemm(d, s);
+  return d;
+}
+static int grad_input(const float* dy, long lddy, const float* W, long ldw, int M, int N, int K, float* dx,
+                      long lddx, int beta, hipStream_t s, const LiveRows* lr = nullptr) {
+  return launch_gemm(desc_grad_input(dy, lddy, W, ldw, M, N, K, dx, lddx, beta, lr), s);
 }
 
 static int grad_bias(const float* dy, int M, int N, long ld, float* db, hipStream_t s) {
@@ -382,33 +390,53 @@ static int encoder_backward_impl(int ne, int cell, int B, int L, int E, int H, c
   const long per_list = 16 + (long)L * B;
   int* buf = nullptr;
   if (use_live) CVAE_TRY(lib_rows(ne * per_list, &buf, s));
+  LiveRows live[SKINNY_MAX_BATCH];
+  const LiveRows* lr[SKINNY_MAX_BATCH];
+  float* dX[SKINNY_MAX_BATCH];
+  const bool dbh_sep = cell == CELL_GRU && !gemm_wide_has_spare_column(H);
+  ZeroBatch zb(s);
   for (int e = 0; e < ne; ++e) {
     const EncBwd& q = ee[e];
-    float* dX = q.scratch + 2 * per_dir;
-    LiveRows live = {nullptr, nullptr};
-    const LiveRows* lr = nullptr;
+    dX[e] = q.scratch + 2 * per_dir;
+    lr[e] = nullptr;
     if (use_live) {
       int* lb = buf + e * per_list;
       CVAE_TRY(launch_live_rows_tm(L, B, q.len, 0, lb + 16, lb, s));
-      live.rows = lb + 16; live.n = lb;
-      lr = &live;
-      CVAE_TRY(launch_zero(dX, (long)L * B * E, s));
+      live[e].rows = lb + 16; live[e].n = lb;
+      lr[e] = &live[e];
+      zb.add(dX[e], (long)L * B * E);
     }
-    for (int d = 0; d < 2; ++d) {
-      const int i = 2 * e + d;
-      const float* W_ih = q.w[4 * d + 0];
-      const float* dgh_eff = (cell == CELL_GRU) ? dgh[i] : dgx[i];
-      // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
-      const float* hprev = r[i].hs + (d ? BH : 0);
-      CVAE_TRY(grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, q.dw[4 * d + 1], 0, s, nullptr, lr));
-      CVAE_TRY(grad_weight(dgx[i], (long)G * H, q.X, E, L * B, G * H, E, q.dw[4 * d + 0], 0, s, q.dw[4 * d + 2], lr));
-      // LSTM: both bias vectors see the same pre-activation gradient
-      if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, L * B, G * H, (long)G * H, q.dw[4 * d + 3], s));
-      else CVAE_TRY(launch_copy(q.dw[4 * d + 3], q.dw[4 * d + 2], (long)G * H, s));
-      CVAE_TRY(grad_input(dgx[i], (long)G * H, W_ih, E, L * B, G * H, E, dX, E, d, s, lr));
-    }
-    CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, q.ids, dX, q.mask, q.mask_rows, demb, s));
+    if (dbh_sep) { zb.add(q.dw[3], (long)G * H); zb.add(q.dw[7], (long)G * H); }
   }
+  CVAE_TRY(zb.flush());
+  // the products of one kind of both directions (and encoders) share a launch (launch_gemm_n)
+  GemmDesc gd[SKINNY_MAX_BATCH];
+  for (int i = 0; i < 2 * ne; ++i) {
+    const int e = i >> 1, d = i & 1;
+    const float* dgh_eff = (cell == CELL_GRU) ? dgh[i] : dgx[i];
+    const float* hprev = r[i].hs + (d ? BH : 0);          // h_{t-1} of step t: forward -> slot t, reverse -> slot t+1
+    gd[i] = desc_grad_weight(dgh_eff, (long)G * H, hprev, H, L * B, G * H, H, ee[e].dw[4 * d + 1], 0,
+                             (cell == CELL_GRU && !dbh_sep) ? ee[e].dw[4 * d + 3] : nullptr, lr[e]);
+  }
+  CVAE_TRY(launch_gemm_n(gd, 2 * ne, s));
+  for (int i = 0; i < 2 * ne; ++i) {
+    const int e = i >> 1, d = i & 1;
+    gd[i] = desc_grad_weight(dgx[i], (long)G * H, ee[e].X, E, L * B, G * H, E, ee[e].dw[4 * d + 0], 0, ee[e].dw[4 * d + 2], lr[e]);
+  }
+  CVAE_TRY(launch_gemm_n(gd, 2 * ne, s));
+  for (int i = 0; i < 2 * ne; ++i) {
+    const int e = i >> 1, d = i & 1;
+    // LSTM: both bias vectors see the same pre-activation gradient
+    if (cell != CELL_GRU) CVAE_TRY(launch_copy(ee[e].dw[4 * d + 3], ee[e].dw[4 * d + 2], (long)G * H, s));
+    else if (dbh_sep) CVAE_TRY(launch_colsum_acc(dgh[i], L * B, G * H, (long)G * H, ee[e].dw[4 * d + 3], s));
+  }
+  for (int d = 0; d < 2; ++d) {                           // direction 1 adds to direction 0's dX
+    for (int e = 0; e < ne; ++e)
+      gd[e] = desc_grad_input(dgx[2 * e + d], (long)G * H, ee[e].w[4 * d + 0], E, L * B, G * H, E, dX[e], E, d, lr[e]);
+    CVAE_TRY(launch_gemm_n(gd, ne, s));
+  }
+  for (int e = 0; e < ne; ++e)
+    CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ee[e].ids, dX[e], ee[e].mask, ee[e].mask_rows, demb, s));
   return 0;
 }
 
@@ -751,32 +779,40 @@ struct DecBwd {
 
 static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go,
                                  const DecBwd* dd, float* demb, hipStream_t s, int skip_prefix = 0) {
+  CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH, "decoder_backward: %d decoders (max %d)", nd, SKINNY_MAX_BATCH);
   const int G = gates_of(cell), T1 = T + 1;
   const long BH = (long)B * Hd, GH = (long)G * Hd;
   RnnBwd r[SKINNY_MAX_BATCH] = {};
   float* dgx[SKINNY_MAX_BATCH]; float* dgh[SKINNY_MAX_BATCH]; float* dX[SKINNY_MAX_BATCH];
+  float* dpre[SKINNY_MAX_BATCH]; float* dhs[SKINNY_MAX_BATCH]; const float* hout[SKINNY_MAX_BATCH];
   LiveRows live_w[SKINNY_MAX_BATCH], live_r[SKINNY_MAX_BATCH];
   const LiveRows* lrw[SKINNY_MAX_BATCH]; const LiveRows* lrr[SKINNY_MAX_BATCH];
+  GemmDesc gd[SKINNY_MAX_BATCH];
   const bool use_live = live_rows_enabled() && (long)T * B >= 1024 && B <= SKINNY_MAX_ROWS;
   const long per_dec = (4L * B + 16 + (long)T * B + (long)T1 * B + 3) / 4 * 4;     // ints per decoder
   int* rows_buf = nullptr;
   if (use_live) {
     CVAE_TRY(lib_rows((long)nd * per_dec, &rows_buf, s));   // shared with the encoder's list: calls are stream-ordered
   }
+  // The bias gradients ride in the weight-gradient products as a ones column where the tiling has a spare column
+  // (gemm_wide), else they are a pass of their own over the pre-activation gradient.
+  const bool dbc_sep = !gemm_wide_has_spare_column(Hd);
+  const bool dbh_sep = cell == CELL_GRU && !gemm_wide_has_spare_column(Hd);
+  ZeroBatch zb(s);                                          // every buffer of this call that must start at zero
   for (int d = 0; d < nd; ++d) {
     const DecBwd& q = dd[d];
     CVAE_REQUIRE(q.w && q.X && q.hs && q.gates && q.final && q.dfinal && q.dinit && q.dw && q.scratch,
                  "decoder_backward: null operand");
     CVAE_REQUIRE(!q.mask_out || q.hdrop, "decoder_backward: hdrop missing");
-    float* dpre = q.scratch;
-    float* dhs = dpre + (long)T * B * E;
-    dgx[d] = dhs + (long)T1 * BH;
+    dpre[d] = q.scratch;
+    dhs[d] = dpre[d] + (long)T * B * E;
+    dgx[d] = dhs[d] + (long)T1 * BH;
     dgh[d] = dgx[d] + (long)T1 * B * GH;
     dX[d] = dgh[d] + (long)T1 * B * GH;
     float* dh0 = dX[d] + (long)T1 * B * 2 * E;
     float* dh_tmp = dh0 + BH; float* dc0 = dh_tmp + BH; float* dc_tmp = dc0 + BH;
     float* whhT = dc_tmp + BH;
-    const float* hout = q.mask_out ? q.hdrop : q.hs + 2 * BH;
+    hout[d] = q.mask_out ? q.hdrop : q.hs + 2 * BH;
     // Rows (t, b) past sentence b's last target receive an exactly zero dfinal row (the loss ignores
     // <pad>): find each sentence's last non-zero step and leave the dead rows out of every product.
     lrw[d] = lrr[d] = nullptr;
@@ -795,37 +831,57 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
       r[d].zero_after = za1;
     }
     // final = tanh(hout W_c^T + b_c)
-    CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre, s));
-    CVAE_TRY(grad_weight(dpre, E, hout, Hd, T * B, E, Hd, q.dw[4], 0, s, nullptr, lrw[d]));
-    CVAE_TRY(grad_bias(dpre, T * B, E, E, q.dw[5], s));
-    CVAE_TRY(launch_zero(dhs, use_live ? (long)T1 * BH : (long)BH, s));
-    CVAE_TRY(grad_input(dpre, E, q.w[4], Hd, T * B, E, Hd, dhs + BH, Hd, 0, s, lrw[d]));
-    if (q.mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs + BH, q.mask_out, dhs + BH, s));
+    CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre[d], s));
+    if (dbc_sep) zb.add(q.dw[5], E);
+    if (dbh_sep) zb.add(q.dw[3], GH);
+    zb.add(dhs[d], use_live ? (long)T1 * BH : (long)BH);
+    if (lrr[d]) zb.add(dX[d], (long)T1 * B * 2 * E);
     r[d].cell = cell; r[d].T = T1; r[d].R = B; r[d].H = Hd; r[d].reverse = 0;
-    r[d].dhs = dhs; r[d].hs = q.hs; r[d].cs = q.cs; r[d].gates = q.gates; r[d].W_hh = q.w[1];
+    r[d].dhs = dhs[d]; r[d].hs = q.hs; r[d].cs = q.cs; r[d].gates = q.gates; r[d].W_hh = q.w[1];
     r[d].dgx = dgx[d]; r[d].dgh = (cell == CELL_GRU) ? dgh[d] : nullptr;
     r[d].dh0 = dh0; r[d].dc0 = dc0; r[d].dh_tmp = dh_tmp; r[d].dc_tmp = dc_tmp; r[d].whhT = whhT;
     if (skip_prefix) {      // internal steps 1..T only; step 0 contributes nothing
-      CVAE_TRY(launch_zero(dgx[d], (long)B * GH, s));
-      if (cell == CELL_GRU) CVAE_TRY(launch_zero(dgh[d], (long)B * GH, s));
-      r[d].T = T; r[d].dhs = dhs + BH; r[d].hs = q.hs + BH; r[d].cs = q.cs ? q.cs + BH : nullptr;
+      zb.add(dgx[d], (long)B * GH);
+      if (cell == CELL_GRU) zb.add(dgh[d], (long)B * GH);
+      r[d].T = T; r[d].dhs = dhs[d] + BH; r[d].hs = q.hs + BH; r[d].cs = q.cs ? q.cs + BH : nullptr;
       r[d].gates = q.gates + (long)B * 4 * Hd; r[d].dgx = dgx[d] + (long)B * GH;
       r[d].dgh = (cell == CELL_GRU) ? dgh[d] + (long)B * GH : nullptr;
       if (r[d].zero_after) r[d].zero_after -= B;          // za (target steps) instead of za + 1
     }
   }
+  CVAE_TRY(zb.flush());
+  // the decoders' products of one kind share a launch (launch_gemm_n)
+  for (int d = 0; d < nd; ++d)
+    gd[d] = desc_grad_weight(dpre[d], E, hout[d], Hd, T * B, E, Hd, dd[d].dw[4], 0, dbc_sep ? nullptr : dd[d].dw[5], lrw[d]);
+  CVAE_TRY(launch_gemm_n(gd, nd, s));
+  if (dbc_sep)
+    for (int d = 0; d < nd; ++d) CVAE_TRY(launch_colsum_acc(dpre[d], T * B, E, E, dd[d].dw[5], s));
+  for (int d = 0; d < nd; ++d)
+    gd[d] = desc_grad_input(dpre[d], E, dd[d].w[4], Hd, T * B, E, Hd, dhs[d] + BH, Hd, 0, lrw[d]);
+  CVAE_TRY(launch_gemm_n(gd, nd, s));
+  for (int d = 0; d < nd; ++d)
+    if (dd[d].mask_out) CVAE_TRY(launch_mul((long)T * BH, dhs[d] + BH, dd[d].mask_out, dhs[d] + BH, s));
   CVAE_TRY(launch_rnn_backward_multi(r, nd, s));
   for (int d = 0; d < nd; ++d) {
-    const DecBwd& q = dd[d];
     const float* dgh_eff = (cell == CELL_GRU) ? dgh[d] : dgx[d];
-    CVAE_TRY(grad_weight(dgh_eff, GH, q.hs, Hd, T1 * B, (int)GH, Hd, q.dw[1], 0, s, nullptr, lrr[d]));
-    CVAE_TRY(grad_weight(dgx[d], GH, q.X, 2L * E, T1 * B, (int)GH, 2 * E, q.dw[0], 0, s, q.dw[2], lrr[d]));
-    if (cell == CELL_GRU) CVAE_TRY(grad_bias(dgh_eff, T1 * B, (int)GH, GH, q.dw[3], s));
-    else CVAE_TRY(launch_copy(q.dw[3], q.dw[2], GH, s));
-    if (lrr[d]) CVAE_TRY(launch_zero(dX[d], (long)T1 * B * 2 * E, s));
-    CVAE_TRY(grad_input(dgx[d], GH, q.w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, s, lrr[d]));
-    CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], q.mask_in, q.dinit, s));
-    CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], q.mask_in, nullptr, demb, s));
+    gd[d] = desc_grad_weight(dgh_eff, GH, dd[d].hs, Hd, T1 * B, (int)GH, Hd, dd[d].dw[1], 0,
+                             (cell == CELL_GRU && !dbh_sep) ? dd[d].dw[3] : nullptr, lrr[d]);
+  }
+  CVAE_TRY(launch_gemm_n(gd, nd, s));
+  for (int d = 0; d < nd; ++d)
+    gd[d] = desc_grad_weight(dgx[d], GH, dd[d].X, 2L * E, T1 * B, (int)GH, 2 * E, dd[d].dw[0], 0, dd[d].dw[2], lrr[d]);
+  CVAE_TRY(launch_gemm_n(gd, nd, s));
+  for (int d = 0; d < nd; ++d) {
+    // LSTM: both bias vectors see the same pre-activation gradient
+    if (cell != CELL_GRU) CVAE_TRY(launch_copy(dd[d].dw[3], dd[d].dw[2], GH, s));
+    else if (dbh_sep) CVAE_TRY(launch_colsum_acc(dgh[d], T1 * B, (int)GH, GH, dd[d].dw[3], s));
+  }
+  for (int d = 0; d < nd; ++d)
+    gd[d] = desc_grad_input(dgx[d], GH, dd[d].w[0], 2L * E, T1 * B, (int)GH, 2 * E, dX[d], 2L * E, 0, lrr[d]);
+  CVAE_TRY(launch_gemm_n(gd, nd, s));
+  for (int d = 0; d < nd; ++d) {
+    CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], dd[d].mask_in, dd[d].dinit, s));
+    CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], dd[d].mask_in, nullptr, demb, s));
   }
   return 0;
 }

@@ -137,6 +137,7 @@ struct GemmDesc {
   const int* rows; const int* nlive; int bound_dim;
 };
 int launch_gemm(const GemmDesc& d, hipStream_t s);
+int launch_gemm_n(const GemmDesc* d, int n, hipStream_t s);     // same-shaped gemm_wide products share one launch
 int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStream_t s);
 bool gemm_wide_has_spare_column(int N);
 
@@ -157,8 +158,11 @@ struct G224Args {
   int ntiles, tile_w, part_ld, min_chunks;   // filled by the launcher
   int vecA, vecB, vecC;
 };
+constexpr int G224_MAX_BATCH = 4;
+struct G224Batch { G224Args a[G224_MAX_BATCH]; };
 long gemm_wide_part_floats(int N, bool extra);
 int launch_gemm_wide(bool a_k_contiguous, G224Args a, hipStream_t s);
+int launch_gemm_wide_n(bool a_k_contiguous, const G224Args* a, int n, hipStream_t s);   // n same-shaped products, one launch
 int persistent_grid_blocks();
 int launch_zero(float* p, long n, hipStream_t s);
 int launch_copy(float* dst, const float* src, long n, hipStream_t s);

@@ -544,4 +544,44 @@ int launch_gemm(const GemmDesc& d, hipStream_t s) {
   return launch_tiled<64, 64>(d, s);
 }
 
+// The gemm_wide form of a product that launch_gemm runs there without any helper launch (else false)
+static bool gemm_wide_form(const GemmDesc& d, G224Args* w) {
+  if (d.nbatch > 0 || d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.B || !d.C) return false;
+  if (d.transB || d.act != ACT_NONE || d.bias) return false;
+  if (d.lda < (d.transA ? d.M : d.K) || d.ldb < d.N || d.ldc < d.N) return false;
+  if (d.colsum_out && !(d.transA && !d.beta && gemm_wide_has_spare_column(d.N))) return false;
+  *w = G224Args{};
+  w->A = d.A; w->lda = d.lda; w->B = d.B; w->ldb = d.ldb; w->C = d.C; w->ldc = d.ldc;
+  w->M = d.M; w->N = d.N; w->K = d.K; w->beta = d.beta; w->extra = d.colsum_out;
+  if (d.rows) {
+    if (!d.nlive || !((d.bound_dim == 1 && !d.transA) || (d.bound_dim == 2 && d.transA))) return false;
+    w->rows = d.rows; w->nlive = d.nlive; w->r0 = 0; w->dev_bound = d.bound_dim; w->a_ind = 1;
+    return true;
+  }
+  if (!d.transA && d.M <= 64 && d.K >= 64) return false;                       // the skinny path's
+  const int wide_max_n = split_bf16_enabled() ? 4096 : 1024;
+  if (d.colsum_out && d.N > 1024) return false;
+  return d.K >= 512 && d.N <= wide_max_n && d.M >= 64;
+}
+
+// n products; those of one shape and form that gemm_wide takes run as ONE launch (launch_gemm_wide_n), anything else
+// one by one.  The two decoders' and the two encoder directions' weight- and input-gradient products come in such sets.
+int launch_gemm_n(const GemmDesc* dd, int n, hipStream_t s) {
+  CVAE_REQUIRE(dd && n >= 1, "gemm_n: no products");
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CVAE_WIDE_BATCH"); on = (e && e[0] == '0') ? 0 : 1; }
+  G224Args w[G224_MAX_BATCH];
+  bool same = on && n >= 2 && n <= G224_MAX_BATCH;
+  for (int i = 0; same && i < n; ++i) {
+    const GemmDesc& d = dd[i];
+    same = gemm_wide_form(d, &w[i]) && d.transA == dd[0].transA && d.M == dd[0].M && d.N == dd[0].N && d.K == dd[0].K &&
+           d.beta == dd[0].beta && (d.colsum_out != nullptr) == (dd[0].colsum_out != nullptr) &&
+           (d.rows != nullptr) == (dd[0].rows != nullptr) && d.bound_dim == dd[0].bound_dim;
+    for (int j = 0; same && j < i; ++j) same = d.C != dd[j].C;                  // distinct outputs
+  }
+  if (same) return launch_gemm_wide_n(!dd[0].transA, w, n, s);
+  for (int i = 0; i < n; ++i) CVAE_TRY(launch_gemm(dd[i], s));
+  return 0;
+}
+
 }  // namespace cvae

@@ -82,7 +82,8 @@ __device__ __forceinline__ WideLayout wide_layout(const G224Args& p, int nblk) {
 
 // NF = 4: 128-column tiles; NF = 7: 224-column tiles (fragments 4,5 from a b64, 6 from a b32)
 template <bool AKC, int NF>
-__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Args p) {
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(G224Batch batch) {
+  const G224Args& p = batch.a[blockIdx.y];       // one product per grid row (launch_gemm_wide_n)
   constexpr int BN = NF * 32;
   __shared__ __attribute__((aligned(16))) float As[2][AKC ? G2_BM * G2_LDA : G2_BK * G2_BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][G2_BK * BN];
@@ -379,7 +380,8 @@ __device__ __forceinline__ void gw_split(const f32x8 v, bf16x8 (&t)[3]) {
 }
 
 template <bool AKC, int NF>
-__global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
+__global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Batch batch) {
+  const G224Args& p = batch.a[blockIdx.y];       // one product per grid row (launch_gemm_wide_n)
   constexpr int BN = NF * 32;
   // LDS, in 16-byte slots: [buf][A hi: 128 rows x 2][A mid][A lo][B hi: BN rows x 2][B mid][B lo]
   constexpr int A_SL = G2_BM * 2, B_SL = BN * 2, BUF_SL = 3 * A_SL + 3 * B_SL;
@@ -673,7 +675,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Args p) {
 }
 
 // C (+)= sum over the ks slabs, in slab order (deterministic).  One thread per (row, 4 columns).
-__global__ __launch_bounds__(256) void gemm_wide_reduce_kernel(G224Args p, int nblk) {
+__global__ __launch_bounds__(256) void gemm_wide_reduce_kernel(G224Batch batch, int nblk) {
+  const G224Args& p = batch.a[blockIdx.y];
   const WideLayout L = wide_layout(p, nblk);
   if (L.ks <= 1 || L.Mlim <= 0 || L.Klim <= 0) return;
   const int ncol = p.N + (p.extra ? 1 : 0);
@@ -713,13 +716,14 @@ static int lib_part(long floats, float** out, hipStream_t s) {
   return 0;
 }
 
-// The ones column (bias gradient / row sums as an extra output column) needs the 224-wide tiling
-// with a balanced tile width below 224: true for N <= 220 and for every N whose 224-tiling is the
-// cheaper one anyway.
+// The ones column (bias gradient / row sums as an extra output column) needs the 224-wide tiling with a balanced
+// tile width of at most 220: taken whenever such a tiling exists (a few idle MFMA columns cost less than the separate
+// pass over A that the caller would launch instead), and for every N whose 224-tiling is the cheaper one anyway.
 static void wide_tiling(int N, bool extra, bool* wide, int* ntiles, int* tile_w) {
   const int n_eff = N + (extra ? 1 : 0);
   const int nt7 = cdiv(n_eff, 224), nt4 = cdiv(n_eff, 128);
-  *wide = (7 * nt7 < 4 * nt4) || (extra && N <= 220);
+  const int tw7 = cdiv(cdiv(N, nt7), 4) * 4;
+  *wide = (7 * nt7 < 4 * nt4) || (extra && tw7 <= 220);
   *ntiles = *wide ? nt7 : nt4;
   *tile_w = cdiv(cdiv(N, *ntiles), 4) * 4;
 }
@@ -729,20 +733,36 @@ bool gemm_wide_has_spare_column(int N) {
   return wide && tw <= 220;
 }
 
-int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
+// n products of one shape (same M, N, K bounds, operand forms and options; different operands) in ONE launch: grid row y
+// runs product y on its share of the persistent grid.  The small products of a training step are bound by the launch
+// itself and by a chain of memory round trips (device-side bound, row list, first chunks), not by their arithmetic: the
+// two decoders' (or the two encoder directions') products of one kind cost one such chain instead of two.
+int launch_gemm_wide_n(bool akc, const G224Args* in, int n, hipStream_t s) {
+  CVAE_REQUIRE(in && n >= 1 && n <= G224_MAX_BATCH, "gemm_wide: %d products in one launch (max %d)", n, G224_MAX_BATCH);
+  G224Batch batch = {};
+  G224Args& a = batch.a[0];
+  a = in[0];
   CVAE_REQUIRE(a.N > 0, "gemm_wide: N=%d", a.N);
   CVAE_REQUIRE(a.extra == nullptr || gemm_wide_has_spare_column(a.N), "gemm_wide: no spare tile column for N=%d", a.N);
-  CVAE_REQUIRE(!a.a_ind || (a.rows && ((akc && a.dev_bound == 1) || (!akc && a.dev_bound == 2))),
-               "gemm_wide: A-row indirection needs the row list and the matching device bound");
+  for (int i = 0; i < n; ++i) {
+    const G224Args& q = in[i];
+    CVAE_REQUIRE(q.M == a.M && q.N == a.N && q.K == a.K && q.dev_bound == a.dev_bound && q.a_ind == a.a_ind &&
+                 (q.extra != nullptr) == (a.extra != nullptr) && q.beta == a.beta && (q.part != nullptr) == (a.part != nullptr),
+                 "gemm_wide: products of one launch differ in shape or form");
+    CVAE_REQUIRE(!q.a_ind || (q.rows && ((akc && q.dev_bound == 1) || (!akc && q.dev_bound == 2))),
+                 "gemm_wide: A-row indirection needs the row list and the matching device bound");
+    CVAE_REQUIRE(n == 1 || !q.part, "gemm_wide: a batched launch takes its slabs from the library");
+  }
   if (a.M <= 0 || a.K <= 0) return 0;
   // balanced n-tiles: 224-wide fragments when that saves MFMA columns, else 128-wide
   const int n_eff = a.N + (a.extra ? 1 : 0);
+  const int nblk = wide_grid_blocks() / n;            // blocks per product
   bool wide;
   wide_tiling(a.N, a.extra != nullptr, &wide, &a.ntiles, &a.tile_w);
   if (!a.extra) {
     // more tiles than resident blocks (one k-range per tile): the launch runs in rounds, so pick the tile width
     // by rounds x columns per tile (8192 x 2048 outputs: 640 tiles of 224 = 2 rounds of 7, 1024 tiles of 128 = 2 of 4)
-    const long mt = cdiv(a.M, G2_BM), nb = wide_grid_blocks();
+    const long mt = cdiv(a.M, G2_BM), nb = nblk;
     const long nt7 = cdiv(a.N, 224), nt4 = cdiv(a.N, 128);
     if (mt * nt7 > nb || mt * nt4 > nb) {
       const double c7 = (double)cdiv(mt * nt7, nb) * 7.0, c4 = (double)cdiv(mt * nt4, nb) * 4.0 * 1.08;
@@ -751,39 +771,52 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
       a.tile_w = cdiv(cdiv(a.N, a.ntiles), 4) * 4;
     }
   }
-  a.vecA = aligned16(a.A) && (a.lda % 4 == 0);
-  a.vecB = aligned16(a.B) && (a.ldb % 4 == 0);
-  a.vecC = aligned16(a.C) && (a.ldc % 4 == 0);
   a.part_ld = (n_eff + 3) / 4 * 4;
   {
     static int mc = 0;
     if (!mc) { const char* e = getenv("CVAE_WIDE_MIN_CHUNKS"); mc = e ? atoi(e) : 4; if (mc < 1 || mc > 256) mc = 4; }
     a.min_chunks = mc;
   }
-  const int nblk = wide_grid_blocks();
   // slabs are only touched when the device picks more than one k-range per tile (same test as the reduction below)
   const bool may_split = (long)cdiv(a.M, G2_BM) * a.ntiles * 2 <= nblk || a.dev_bound;
-  if (!a.part && may_split) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &a.part, s));
-  const dim3 grid(nblk), block(256);
+  float* part = a.part;
+  if (!part && may_split) CVAE_TRY(lib_part(gemm_wide_part_floats(a.N, a.extra != nullptr), &part, s));
+  bool vec = true;
+  double work = 0.0;
+  for (int i = 0; i < n; ++i) {
+    G224Args& q = batch.a[i];
+    if (i) {
+      q = in[i];
+      q.ntiles = a.ntiles; q.tile_w = a.tile_w; q.part_ld = a.part_ld; q.min_chunks = a.min_chunks;
+    }
+    q.vecA = aligned16(q.A) && (q.lda % 4 == 0);
+    q.vecB = aligned16(q.B) && (q.ldb % 4 == 0);
+    q.vecC = aligned16(q.C) && (q.ldc % 4 == 0);
+    vec = vec && q.vecA && q.vecB;
+    // every product owns nblk tiles' worth of the slab buffer (at most nblk (tile, k-range) items have slabs)
+    q.part = part ? part + (long)i * nblk * G2_BM * a.part_ld : nullptr;
+    double pm = q.M, pk = q.K;
+    if (q.dev_bound == 1 && q.prof_units > 0) pm = (double)q.prof_units;
+    if (q.dev_bound == 2 && q.prof_units > 0) pk = (double)q.prof_units;
+    work += 2.0 * pm * q.N * pk;
+  }
+  const dim3 grid(nblk, n), block(256);
   {
-    double pm = a.M, pk = a.K;
-    if (a.dev_bound == 1 && a.prof_units > 0) pm = (double)a.prof_units;
-    if (a.dev_bound == 2 && a.prof_units > 0) pk = (double)a.prof_units;
-    ProfScope prof(PK_GEMM_WIDE, s, 2.0 * pm * a.N * pk);
-    if (split_bf16_enabled() && a.vecA && a.vecB) {
+    ProfScope prof(PK_GEMM_WIDE, s, work);
+    if (split_bf16_enabled() && vec) {
       if (akc) {
-        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 7>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 4>), grid, block, 0, s, a);
+        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 7>), grid, block, 0, s, batch);
+        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<true, 4>), grid, block, 0, s, batch);
       } else {
-        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 7>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 4>), grid, block, 0, s, a);
+        if (wide) hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 7>), grid, block, 0, s, batch);
+        else hipLaunchKernelGGL((gemm_wide_bf3_kernel<false, 4>), grid, block, 0, s, batch);
       }
     } else if (akc) {
-      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<true, 7>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, block, 0, s, a);
+      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<true, 7>), grid, block, 0, s, batch);
+      else hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, block, 0, s, batch);
     } else {
-      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<false, 7>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((gemm_wide_kernel<false, 4>), grid, block, 0, s, a);
+      if (wide) hipLaunchKernelGGL((gemm_wide_kernel<false, 7>), grid, block, 0, s, batch);
+      else hipLaunchKernelGGL((gemm_wide_kernel<false, 4>), grid, block, 0, s, batch);
     }
   }
   CVAE_LAUNCH_CHECK("gemm_wide_kernel");
@@ -791,11 +824,13 @@ int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) {
   if (may_split) {
     const long total = (long)a.M * (a.part_ld / 4);
     int rb = (int)((total + 255) / 256);
-    if (rb > 2048) rb = 2048;
-    hipLaunchKernelGGL(gemm_wide_reduce_kernel, dim3(rb), dim3(256), 0, s, a, nblk);
+    if (rb > 2048 / n) rb = 2048 / n;
+    hipLaunchKernelGGL(gemm_wide_reduce_kernel, dim3(rb, n), dim3(256), 0, s, batch, nblk);
     CVAE_LAUNCH_CHECK("gemm_wide_reduce_kernel");
   }
   return 0;
 }
+
+int launch_gemm_wide(bool akc, G224Args a, hipStream_t s) { return launch_gemm_wide_n(akc, &a, 1, s); }
 
 }  // namespace cvae

@@ -1,42 +1,33 @@
-"""Diagnostic: where does the HOST time of a training step go?  Accumulates wall time spent inside
-each C-ABI call (launch issue cost, no sync) and prints a cProfile summary of the Python side."""
-import cProfile, collections, os, pstats, sys, time
+"""Diagnostic: where the HOST spends a training step (cProfile over n steps; the device runs asynchronously, so at the
+small shapes this is the step time).  SHAPE=ptb|yelp|switchboard python scripts/host_profile.py [n]"""
+import cProfile, os, pstats, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
 import torch
-from cvae_amd import _lib, data, harness, ops
+from cvae_amd import _lib, data, harness
 dev = torch.device('cuda:0'); _lib.init(0)
-cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
-shape = dict(data.SHAPES['yelp'])
-if len(sys.argv) > 2:
-    shape['V'] = int(sys.argv[2])
-hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'])
-tr = harness.Trainer(hp, dev, seed=0); tr.iter_num = 20000
-B = 32; n = 13
-corpus = data.Corpus(data.synthetic_sentences(B * n, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
-batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev) for i in range(n)]
-for i in range(3): tr.train_step(batches[i])
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+shape = data.SHAPES[os.environ.get('SHAPE', 'ptb')]
+hp = harness.HParams(model='vae-couple', cell='lstm', V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'], batch_size=32)
+tr = harness.Trainer(hp, dev, seed=0)
+corpus = data.Corpus(data.synthetic_sentences(256, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
+batches = [harness.text_batch(corpus, range(i * 32, (i + 1) * 32), dev) for i in range(8)]
+for i in range(5):
+    tr.train_step(batches[i % 8])
 torch.cuda.synchronize()
-
-acc = collections.defaultdict(lambda: [0, 0.0])
-real_call = ops.call
-def timed_call(name, *a):
-    t = time.perf_counter()
-    r = real_call(name, *a)
-    e = acc[name]; e[0] += 1; e[1] += time.perf_counter() - t
-    return r
-ops.call = timed_call
 t0 = time.perf_counter()
-for i in range(3, 13): tr.train_step(batches[i])
+for i in range(n):
+    tr.train_step(batches[i % 8])
 t1 = time.perf_counter()
 torch.cuda.synchronize()
-print('host issue %.2f ms/step' % ((t1 - t0) * 100))
-tot = 0.0
-for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    print('  %-34s %5.1f calls/step  %8.3f ms/step  %7.1f us/call' % (k, c / 10, t * 100, t / c * 1e6)); tot += t
-print('  total inside C ABI: %.2f ms/step' % (tot * 100))
-ops.call = real_call
-pr = cProfile.Profile(); pr.enable()
-for i in range(3, 13): tr.train_step(batches[i])
-pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('tottime').print_stats(25)
+t2 = time.perf_counter()
+print('host issue %.3f ms/step, with device drain %.3f ms/step' % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+pr = cProfile.Profile()
+pr.enable()
+for i in range(n):
+    tr.train_step(batches[i % 8])
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(45)
+st.sort_stats('cumulative').print_stats(60)

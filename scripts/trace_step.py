@@ -1,19 +1,16 @@
-"""Diagnostic: the kernel sequence of ONE training step (between two clip_adam launches) from a rocprofv3 kernel trace.
-usage: python scripts/trace_step.py <kernel_trace.csv> [which_step]"""
+"""Diagnostic: every launch of the LAST complete training step of a kernel trace (the launches between the last two
+`clip_adam_kernel`s), in order, with its duration and the idle gap before it:
+python scripts/trace_step.py <kernel_trace.csv>"""
 import csv, sys
-rows = []
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'],
-                     r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', ''))))
-rows.sort()
-marks = [i for i, r in enumerate(rows) if 'clip_adam' in r[2]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 2
-a, b = marks[k] + 1, marks[k + 1] + 1
-t0 = rows[a][0]
-prev = rows[a - 1][1]
-for s, e, n, g, w in rows[a:b]:
-    print('%9.1f  +%6.1f  %8.1f us  grid %8s/%-5s %s' % ((s - t0) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, g, w,
-                                                     n.replace('void ', '').replace('cvae::', '')[:90]))
-    prev = e
-print('step span %.1f us' % ((rows[b - 1][1] - rows[a - 1][1]) / 1e3))
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+ends = [i for i, r in enumerate(rows) if 'clip_adam_kernel' in r['Kernel_Name']]
+a, b = ends[-2] + 1, ends[-1] + 1
+prev = int(rows[a - 1]['End_Timestamp'])
+busy = gap = 0.0
+for i, r in enumerate(rows[a:b]):
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    name = r['Kernel_Name'].replace('cvae::', '').replace('void ', '')
+    print('%3d %8.1f us  gap %6.1f  grid %-8s %s' % (i, (e - s) / 1e3, (s - prev) / 1e3, r.get('Grid_Size_X', r.get('Grid_Size', '')), name[:70]))
+    busy += (e - s) / 1e3; gap += max(0, s - prev) / 1e3
+    prev = max(prev, e)
+print('launches %d  busy %.1f us  gaps %.1f us' % (b - a, busy, gap))
