@@ -788,6 +788,8 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   LiveRows live_w[SKINNY_MAX_BATCH], live_r[SKINNY_MAX_BATCH];
   const LiveRows* lrw[SKINNY_MAX_BATCH]; const LiveRows* lrr[SKINNY_MAX_BATCH];
   GemmDesc gd[SKINNY_MAX_BATCH];
+  const float* nz_x[SKINNY_MAX_BATCH]; int64_t* nz_za[SKINNY_MAX_BATCH];
+  LiveRowsJob jobs[2 * SKINNY_MAX_BATCH];
   const bool use_live = live_rows_enabled() && (long)T * B >= 1024 && B <= SKINNY_MAX_ROWS;
   const long per_dec = (4L * B + 16 + (long)T * B + (long)T1 * B + 3) / 4 * 4;     // ints per decoder
   int* rows_buf = nullptr;
@@ -821,17 +823,15 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
       int64_t* za = reinterpret_cast<int64_t*>(buf);            // [B] last live target step + 1
       int64_t* za1 = za + B;                                    // [B] the same in recurrence steps (prefix step first)
       int* cnt = buf + 4 * B;
-      CVAE_TRY(launch_last_nonzero_step(T, B, E, q.dfinal, za, s));
-      CVAE_TRY(launch_add_i64(za, 1, B, za1, s));
-      CVAE_TRY(launch_live_rows_tm(T, B, za, 0, cnt + 16, cnt, s));
-      CVAE_TRY(launch_live_rows_tm(T1, B, za1, 0, cnt + 16 + (long)T * B, cnt + 1, s));
+      zb.add(reinterpret_cast<float*>(za), 2L * B);
+      nz_x[d] = q.dfinal; nz_za[d] = za;
+      jobs[2 * d] = LiveRowsJob{T, 0, za, cnt + 16, cnt, nullptr};
+      jobs[2 * d + 1] = LiveRowsJob{T1, 1, za, cnt + 16 + (long)T * B, cnt + 1, za1};
       live_w[d].rows = cnt + 16; live_w[d].n = cnt;
       live_r[d].rows = cnt + 16 + (long)T * B; live_r[d].n = cnt + 1;
       lrw[d] = &live_w[d]; lrr[d] = &live_r[d];
       r[d].zero_after = za1;
     }
-    // final = tanh(hout W_c^T + b_c)
-    CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, q.final, q.dfinal, dpre[d], s));
     if (dbc_sep) zb.add(q.dw[5], E);
     if (dbh_sep) zb.add(q.dw[3], GH);
     zb.add(dhs[d], use_live ? (long)T1 * BH : (long)BH);
@@ -850,6 +850,13 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
     }
   }
   CVAE_TRY(zb.flush());
+  if (use_live) {                                           // one scan and one list-building launch for all decoders
+    CVAE_TRY(launch_last_nonzero_step_n(nd, T, B, E, nz_x, nz_za, s));
+    CVAE_TRY(launch_live_rows_tm_n(jobs, 2 * nd, B, s));
+  }
+  // final = tanh(hout W_c^T + b_c)
+  for (int d = 0; d < nd; ++d)
+    CVAE_TRY(launch_act_bwd((long)T * B * E, ACT_TANH, dd[d].final, dd[d].dfinal, dpre[d], s));
   // the decoders' products of one kind share a launch (launch_gemm_n)
   for (int d = 0; d < nd; ++d)
     gd[d] = desc_grad_weight(dpre[d], E, hout[d], Hd, T * B, E, Hd, dd[d].dw[4], 0, dbc_sep ? nullptr : dd[d].dw[5], lrw[d]);

@@ -569,8 +569,17 @@ __global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, fl
   if (i >= nlive) return;
   const int rb = (nlive + CE_ROWS - 1) / CE_ROWS;
   const int nsplit = ce_pick_split(rb, (p.V + CE_TN - 1) / CE_TN, p.cap, nblk);
+  // two passes with independent loads (a serial merge of up to 64 partials was a 17 us chain of load + exp round trips)
+  const float* pm = p.pm + i;
+  const float* ps = p.ps + i;
   float m = -INFINITY, s = 0.f;
-  for (int k = 0; k < nsplit; ++k) lse_merge2(m, s, p.pm[(long)k * p.pstride + i], p.ps[(long)k * p.pstride + i]);
+#pragma unroll 8
+  for (int k = 0; k < nsplit; ++k) m = fmaxf(m, pm[(long)k * p.pstride]);
+#pragma unroll 8
+  for (int k = 0; k < nsplit; ++k) {
+    const float m2 = pm[(long)k * p.pstride], s2 = ps[(long)k * p.pstride];
+    s += (m2 == m) ? s2 : s2 * __expf(m2 - m);
+  }
   const float l = m + logf(s);
   const int n = p.rows[i];
   lse[n] = l;
@@ -700,7 +709,10 @@ static long live_rows_for_profile(const int* nlive, long N, hipStream_t s) {
 
 // X [nseg*TR, E]; tgt [TR]; loss, lse [nseg*TR]
 static long ce_ldp(int V) { return (long)cdiv(V, CE_TN) * CE_TN; }
-long ce_fast_logits_floats(long N, int V) { return ((N + CE_ROWS - 1) / CE_ROWS * CE_ROWS) * ce_ldp(V); }
+// saved logits of the live rows, then the live-row list and its count (the backward pass reuses them: no second scan)
+static long ce_logits_only_floats(long N, int V) { return ((N + CE_ROWS - 1) / CE_ROWS * CE_ROWS) * ce_ldp(V); }
+long ce_fast_logits_floats(long N, int V) { return ce_logits_only_floats(N, V) + N + 16; }
+static int* ce_saved_rows(float* logits, long N, int V) { return reinterpret_cast<int*>(logits + ce_logits_only_floats(N, V)); }
 
 // logits: null, or ce_fast_logits_floats(N, V) floats (16-byte aligned) that receive the logits of the live rows
 int launch_ce_fast_forward(const float* X, const float* W, const float* bias, const int64_t* tgt, int64_t pad,
@@ -714,6 +726,10 @@ int launch_ce_fast_forward(const float* X, const float* W, const float* bias, co
   int* counts = rows + N;
   int* nlive = counts + ce_counts_slots(N) - 4;
   float* tl = ws + N + ce_counts_slots(N);
+  if (logits) {                                  // the list lives with the saved logits (launch_ce_fast_backward)
+    rows = ce_saved_rows(logits, N, V);
+    nlive = rows + N;
+  }
   CeArgs a = {};
   a.X = X; a.W = W; a.bias = bias; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
   a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
@@ -782,7 +798,12 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
     P = logits;
   }
   part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(part) + 15) & ~(uintptr_t)15);
-  CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, nullptr, nullptr, nullptr, s));
+  if (logits) {                                  // the forward pass left the list behind the logits it saved
+    rows = ce_saved_rows(logits, N, V);
+    nlive = rows + N;
+  } else {
+    CVAE_TRY(launch_rows(tgt, pad, N, TR, rows, counts, nlive, nullptr, nullptr, nullptr, s));
+  }
   CeArgs a = {};
   a.X = X; a.W = W; a.bias = bias; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
   a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;

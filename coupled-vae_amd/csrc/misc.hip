@@ -736,12 +736,19 @@ int launch_beam_backtrack(int B, int K, int T, const int* bp, const int* tok, co
 
 // Time-major list of the (t, b) pairs with t < za[b] + off, as row ids k = t*B + b in ascending order,
 // and its length.  One block; T is walked in slabs of 256 steps with an LDS scan of the per-step counts.
-__global__ __launch_bounds__(256) void live_rows_tm_kernel(int T, int B, const int64_t* __restrict__ za, int off,
-                                                           int* __restrict__ rows, int* __restrict__ count) {
+// One block per job: the time-major list of the rows (t, b) with t < za[b] + off, their count, and optionally
+// za_out[b] = za[b] + off (the same bound as an array for the backward recurrence).
+__global__ __launch_bounds__(256) void live_rows_tm_kernel(LiveRowsBatch batch) {
+  const LiveRowsJob& q = batch.j[blockIdx.x];
+  const int T = q.T, B = batch.B, off = q.off;
+  const int64_t* __restrict__ za = q.za;
+  int* __restrict__ rows = q.rows;
   __shared__ int sc[256];
   __shared__ int base;
   const int tid = threadIdx.x;
   if (tid == 0) base = 0;
+  if (q.za_out)
+    for (int b = tid; b < B; b += 256) q.za_out[b] = za[b] + off;
   __syncthreads();
   for (int t0 = 0; t0 < T; t0 += 256) {
     const int t = t0 + tid;
@@ -764,13 +771,23 @@ __global__ __launch_bounds__(256) void live_rows_tm_kernel(int T, int B, const i
     if (tid == 255) base += sc[255];
     __syncthreads();
   }
-  if (tid == 0) *count = base;
+  if (tid == 0) *q.count = base;
 }
-int launch_live_rows_tm(int T, int B, const int64_t* za, int off, int* rows, int* count, hipStream_t s) {
-  CVAE_REQUIRE(T >= 0 && B > 0 && za && rows && count, "live_rows_tm: bad arguments");
-  hipLaunchKernelGGL(live_rows_tm_kernel, dim3(1), dim3(256), 0, s, T, B, za, off, rows, count);
+int launch_live_rows_tm_n(const LiveRowsJob* jobs, int n, int B, hipStream_t s) {
+  CVAE_REQUIRE(jobs && n >= 1 && n <= LiveRowsBatch::MAX && B > 0, "live_rows_tm: bad arguments");
+  LiveRowsBatch batch = {};
+  batch.B = B;
+  for (int i = 0; i < n; ++i) {
+    CVAE_REQUIRE(jobs[i].T >= 0 && jobs[i].za && jobs[i].rows && jobs[i].count, "live_rows_tm: bad job");
+    batch.j[i] = jobs[i];
+  }
+  hipLaunchKernelGGL(live_rows_tm_kernel, dim3(n), dim3(256), 0, s, batch);
   CVAE_LAUNCH_CHECK("live_rows_tm_kernel");
   return 0;
+}
+int launch_live_rows_tm(int T, int B, const int64_t* za, int off, int* rows, int* count, hipStream_t s) {
+  const LiveRowsJob j = {T, off, za, rows, count, nullptr};
+  return launch_live_rows_tm_n(&j, 1, B, s);
 }
 
 __global__ void add_i64_kernel(const int64_t* __restrict__ x, int64_t c, int n, int64_t* __restrict__ y) {
@@ -785,11 +802,11 @@ int launch_add_i64(const int64_t* x, int64_t c, int n, int64_t* y, hipStream_t s
 }
 
 // za[r] = max(za[r], 1 + the last step t with a non-zero entry in x[t, r, :]); za zeroed by the caller.
-// grid (R, time chunks).
-__global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, int H, int tchunk,
-                                                                const float* __restrict__ x,
-                                                                unsigned long long* __restrict__ za) {
+// grid (R, time chunks, tensors).
+struct LastNzBatch { static constexpr int MAX = 4; const float* x[MAX]; unsigned long long* za[MAX]; };
+__global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, int H, int tchunk, LastNzBatch batch) {
   __shared__ int smax[4];
+  const float* __restrict__ x = batch.x[blockIdx.z];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
   int best = 0;
@@ -805,18 +822,27 @@ __global__ __launch_bounds__(256) void last_nonzero_step_kernel(int T, int R, in
   __syncthreads();
   if (tid == 0) {
     const int m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-    if (m > 0) atomicMax(za + r, (unsigned long long)m);
+    if (m > 0) atomicMax(batch.za[blockIdx.z] + r, (unsigned long long)m);
   }
+}
+// n tensors [T, R, H] in one launch; every za[i] (int64 [R]) must already be zero
+int launch_last_nonzero_step_n(int n, int T, int R, int H, const float* const* x, int64_t* const* za, hipStream_t s) {
+  CVAE_REQUIRE(n >= 1 && n <= LastNzBatch::MAX && T > 0 && R > 0 && H > 0 && x && za, "last_nonzero_step: bad arguments");
+  LastNzBatch batch = {};
+  for (int i = 0; i < n; ++i) {
+    CVAE_REQUIRE(x[i] && za[i], "last_nonzero_step: null operand");
+    batch.x[i] = x[i]; batch.za[i] = reinterpret_cast<unsigned long long*>(za[i]);
+  }
+  const int tchunk = cdiv(T, 32);
+  hipLaunchKernelGGL(last_nonzero_step_kernel, dim3(R, cdiv(T, tchunk), n), dim3(256), 0, s, T, R, H, tchunk, batch);
+  CVAE_LAUNCH_CHECK("last_nonzero_step_kernel");
+  return 0;
 }
 // za (int64 [R]) is zeroed here
 int launch_last_nonzero_step(int T, int R, int H, const float* x, int64_t* za, hipStream_t s) {
   CVAE_REQUIRE(T > 0 && R > 0 && H > 0 && x && za, "last_nonzero_step: bad arguments");
   CVAE_TRY(launch_zero(reinterpret_cast<float*>(za), 2L * R, s));
-  const int tchunk = cdiv(T, 32);
-  hipLaunchKernelGGL(last_nonzero_step_kernel, dim3(R, cdiv(T, tchunk)), dim3(256), 0, s, T, R, H, tchunk, x,
-                     reinterpret_cast<unsigned long long*>(za));
-  CVAE_LAUNCH_CHECK("last_nonzero_step_kernel");
-  return 0;
+  return launch_last_nonzero_step_n(1, T, R, H, &x, &za, s);
 }
 
 // logits[b, t, v] = tmp[t*B + b, v]

@@ -48,6 +48,11 @@ int launch_argmax_rows(int B, int V, const float* logits, long ld, int mask_id, 
                        long out_off, int64_t* cur, hipStream_t s);
 int launch_add_i64(const int64_t* x, int64_t c, int n, int64_t* y, hipStream_t s);
 int launch_live_rows_tm(int T, int B, const int64_t* za, int off, int* rows, int* count, hipStream_t s);
+// several lists over the same batch of B rows in one launch; za_out (optional): za + off as an array
+struct LiveRowsJob { int T; int off; const int64_t* za; int* rows; int* count; int64_t* za_out; };
+struct LiveRowsBatch { static constexpr int MAX = 8; LiveRowsJob j[MAX]; int B; };
+int launch_live_rows_tm_n(const LiveRowsJob* jobs, int n, int B, hipStream_t s);
+int launch_last_nonzero_step_n(int n, int T, int R, int H, const float* const* x, int64_t* const* za, hipStream_t s);
 int launch_last_nonzero_step(int T, int R, int H, const float* x, int64_t* za, hipStream_t s);
 int launch_logits_bt(int T, int B, long V, const float* tmp, float* out, hipStream_t s);
 int launch_reparam_fwd(const float* mu, const float* sigma, const float* eps, int n, int B, int Z, float* z,

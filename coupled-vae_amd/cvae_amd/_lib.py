@@ -108,7 +108,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """The current torch stream's hipStream_t (the raw getter: torch.cuda.current_stream() builds a Stream object
+    for ~9 us of host time per call, ~0.25 ms of a 2 ms step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

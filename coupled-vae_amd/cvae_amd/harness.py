@@ -225,11 +225,18 @@ class FlatAdam(object):
         self.steps += 1
 
 
+def _set_mode(model, training):
+    """model.train(training), skipped when the flag already holds (the recursive walk over the sub-modules costs
+    ~0.15 ms of host time per step, and the small shapes are bound by the host)."""
+    if any(m.training != training for m in model.modules()):
+        model.train(training)
+
+
 class Trainer(object):
     def __init__(self, hp, device, seed=0, model=None):
         self.hp, self.device = hp, device
         self.model = model if model is not None else build_model(hp, device, seed)
-        self.model.train(True)
+        _set_mode(self.model, True)
         self.opt = FlatAdam(self.model, hp)
         self.iter_num = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -290,7 +297,7 @@ class Trainer(object):
 
     def forward_backward(self, batch):
         self.iter_num += 1
-        self.model.train(True)
+        _set_mode(self.model, True)
         self.opt.zero_grad()
         # every term below is a batch mean: the model may leave its per-row outputs in its own (length-sorted)
         # processing order (modules.RowOrder) instead of un-permuting each of them
@@ -343,7 +350,7 @@ class Trainer(object):
         """batches: iterable of batch dicts -- this rank's shard, or with settings.shard_samples the
         SAME batches on every rank (the K samples are sharded inside test_lm instead).  Returns
         corpus metrics (nll, xent, kl, ppl), identical on every rank."""
-        self.model.train(False)
+        _set_mode(self.model, False)
         hp = self.hp
         acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # sum nll, xent, kl, len+1, count
         per_sentence = []
@@ -365,20 +372,20 @@ class Trainer(object):
             dist_utils.reduce_sums_(acc)
         a = acc.tolist()
         self.check_kernels(sync=True)
-        self.model.train(True)
+        _set_mode(self.model, True)
         return dict(nll=a[0] / a[4], xent=a[1] / a[4], kl=a[2] / a[4], ppl=math.exp(a[0] / a[3]),
                     n=int(a[4])), per_sentence
 
     def estimate_mi(self, batches, n_sample=100):
         """CV/Experiment.py:1453-1503: whole batches (the estimator depends on batch
         composition) are sharded over ranks; final reduction of (sum mi, count)."""
-        self.model.train(False)
+        _set_mode(self.model, False)
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         for b in batches:
             mi, _ = self.model.estimate_mi(go=b['go'], sent_len=b['len'], bare=b['bare'], n_sample=n_sample)
             acc += torch.stack([mi.sum().double(), torch.tensor(float(mi.numel()), device=self.device).double()])
         dist_utils.reduce_sums_(acc)
-        self.model.train(True)
+        _set_mode(self.model, True)
         a = acc.tolist()
         self.check_kernels(sync=True)
         return a[0] / max(a[1], 1.0)

@@ -164,6 +164,7 @@ class LazyLogits(object):
     def __init__(self, final, weight, bias, n_sent, order=None):
         self.final, self.weight, self.bias, self.n_sent = final, weight, bias, n_sent
         self.order = order            # RowOrder the rows of `final` are in (None: the caller's order)
+        self.shared = None            # dict shared with the sibling decoder's logits (decode_pair): targets built once
         self.always_restore = False   # True: per-sentence sums go back to the caller's order whatever the settings say
 
     @property
@@ -228,7 +229,7 @@ class SeqLoss(nn.Module):
         tgt = gts[:logits.n_sent]
         if logits.order is not None:
             tgt = logits.order.targets(tgt)
-        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad)
+        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad, cache=logits.shared)
         if logits.order is not None:
             sent = sent.index_select(0, logits.order.res_idx) if logits.always_restore else logits.order.back(sent)
         if keep_batch:
@@ -385,8 +386,10 @@ def decode_pair(dec_a, dec_b, init_a, init_b, helper, order=None):
         specs.append((init, mi, mo, w))
     cell = ops.LSTM if dec_a.use_lstm else ops.GRU
     fa, fb = ops.decoder_pair(cell, helper, dec_a.Embedding.weight, specs)
-    return (LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B, order),
-            LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B, order))
+    la = LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B, order)
+    lb = LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B, order)
+    la.shared = lb.shared = {}
+    return la, lb
 
 
 def to_init(seq, x):

@@ -539,9 +539,18 @@ class ProjCEFn(torch.autograd.Function):
         return dfinal, dW, db, None, None
 
 
-def proj_ce(final, W, b, eos, pad):
-    """final (T,R,E), eos (B,T) with R % B == 0 -> (R,)."""
-    tgt = targets_time_major(eos, final.shape[1])
+def proj_ce(final, W, b, eos, pad, cache=None):
+    """final (T,R,E), eos (B,T) with R % B == 0 -> (R,).  `cache`: a dict shared by the losses of one forward pass
+    (the two decoders of a training step read the same targets): the time-major targets are built once."""
+    R = final.shape[1]
+    if cache is None:
+        tgt = targets_time_major(eos, R)
+    else:
+        key = ('tgt_tm', eos.data_ptr(), tuple(eos.shape), tuple(eos.stride()), eos._version, R)
+        hit = cache.get(key)
+        if hit is None:
+            hit = cache[key] = (targets_time_major(eos, R), eos)      # holds `eos`: its storage stays pinned
+        tgt = hit[0]
     return ProjCEFn.apply(final, W, b, tgt, pad)
 
 
