@@ -990,6 +990,38 @@ int cvae_projce_forward_train(const float* final, const float* W, const float* b
   return projce_forward_impl(final, W, b, tgt, pad, nseg, T, R, E, V, loss_row, lse, sent, ws, logits, stream);
 }
 
+// nd decoders over the same targets (Decoder + DecoderCouple of one training step), saved-logits path, E <= 200
+int cvae_projce_forward_train_n(int nd, const float* const* final, const float* const* W, const float* const* b,
+                                const int64_t* tgt, int64_t pad, int T, int R, int E, int64_t V,
+                                float* const* loss_row, float* const* lse, float* const* sent, float* const* ws,
+                                float* const* logits, void* stream) {
+  hipStream_t s = S(stream);
+  CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH && T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V > 0 &&
+               V < (1LL << 31) && ce_fast_supported(E), "projce_forward_train_n: bad shape");
+  CVAE_REQUIRE(final && W && b && tgt && loss_row && lse && sent && ws && logits, "projce_forward_train_n: null operand");
+  const long N = (long)T * R;
+  if (N == 0) return 0;
+  CVAE_TRY(launch_ce_fast_forward_n(nd, final, W, b, tgt, pad, N, N, E, (int)V, loss_row, lse, ws, logits, s));
+  for (int d = 0; d < nd; ++d) {
+    CVAE_REQUIRE(sent[d], "projce_forward_train_n: null operand");
+    CVAE_TRY(launch_sum_time(loss_row[d], T, R, sent[d], s));
+  }
+  return 0;
+}
+int64_t cvae_projce_backward_saved_n_workspace(int64_t E) {
+  return ce_fast_supported((int)E) ? gemm_wide_part_floats(200, true) + 32 : 0;
+}
+int cvae_projce_backward_saved_n(int nd, const float* const* final, const float* const* W, const float* const* b,
+                                 const int64_t* tgt, int64_t pad, const float* const* lse, const float* const* gsent,
+                                 int T, int R, int E, int64_t V, float* const* dfinal, float* const* dW,
+                                 float* const* db, float* ws, float* const* logits, void* stream) {
+  CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH && T >= 0 && R >= 0 && (int64_t)T * R < (1LL << 31) && V > 0 &&
+               V < (1LL << 31) && ce_fast_supported(E), "projce_backward_saved_n: bad shape");
+  const long N = (long)T * R;
+  return launch_ce_fast_backward_n(nd, final, W, b, tgt, pad, lse, gsent, N, N, R, E, (int)V, dfinal, dW, db, ws,
+                                   logits, S(stream));
+}
+
 int cvae_split_bf16(int on) { return split_bf16_set(on); }
 int64_t cvae_stream_rnn_min_bytes(int64_t bytes) { return stream_rnn_min_weight_bytes(bytes); }
 

@@ -32,19 +32,21 @@ constexpr int CE_BIAS_COL = 200;
 
 // ------------------------------------------------------------------------------------------
 // live-row list
+// per-row outputs that start at zero (dead rows: loss, lse; every row: tl), for every decoder that shares the list
+struct CeRowsOut { static constexpr int MAX = 4; int n; float* loss[MAX]; float* lse[MAX]; float* tl[MAX]; };
 __global__ __launch_bounds__(1024) void ce_rows_count_kernel(int N, int TR, const int64_t* __restrict__ tgt,
-                                                             int64_t pad, int* __restrict__ counts,
-                                                             float* __restrict__ loss, float* __restrict__ lse,
-                                                             float* __restrict__ tl) {
+                                                             int64_t pad, int* __restrict__ counts, CeRowsOut o) {
   __shared__ int wc[16];
   const int n = blockIdx.x * 1024 + threadIdx.x;
   const bool live = n < N && tgt[n % TR] != pad;
   if (n < N) {
-    if (!live) {
-      if (loss) loss[n] = 0.f;
-      if (lse) lse[n] = 0.f;
+    for (int i = 0; i < o.n; ++i) {
+      if (!live) {
+        if (o.loss[i]) o.loss[i][n] = 0.f;
+        if (o.lse[i]) o.lse[i][n] = 0.f;
+      }
+      if (o.tl[i]) o.tl[i][n] = 0.f;
     }
-    if (tl) tl[n] = 0.f;
   }
   const unsigned long long b = __ballot(live);
   if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
@@ -647,14 +649,20 @@ long ce_fast_workspace_floats(long N, int V) {
   return ce_fwd_base_floats(N, V) + bf3_presplit_floats(208, V);       // + the split image of W (bf16x3 path)
 }
 
-static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* rows, int* counts, int* nlive,
-                       float* loss, float* lse, float* tl, hipStream_t s) {
+static int launch_rows_n(const int64_t* tgt, int64_t pad, long N, long TR, int* rows, int* counts, int* nlive,
+                         const CeRowsOut& o, hipStream_t s) {
   const int nb = cdiv(N, 1024);
-  hipLaunchKernelGGL(ce_rows_count_kernel, dim3(nb), dim3(1024), 0, s, (int)N, (int)TR, tgt, pad, counts, loss, lse, tl);
+  hipLaunchKernelGGL(ce_rows_count_kernel, dim3(nb), dim3(1024), 0, s, (int)N, (int)TR, tgt, pad, counts, o);
   CVAE_LAUNCH_CHECK("ce_rows_count_kernel");
   hipLaunchKernelGGL(ce_rows_write_kernel, dim3(nb), dim3(1024), 0, s, (int)N, (int)TR, tgt, pad, counts, rows, nlive);
   CVAE_LAUNCH_CHECK("ce_rows_write_kernel");
   return 0;
+}
+static int launch_rows(const int64_t* tgt, int64_t pad, long N, long TR, int* rows, int* counts, int* nlive,
+                       float* loss, float* lse, float* tl, hipStream_t s) {
+  CeRowsOut o = {};
+  o.n = 1; o.loss[0] = loss; o.lse[0] = lse; o.tl[0] = tl;
+  return launch_rows_n(tgt, pad, N, TR, rows, counts, nlive, o, s);
 }
 
 template <bool GRAD, bool SAVE = false>
@@ -835,6 +843,106 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
     gw.extra = db; gw.beta = 1; gw.part = part; gw.prof_units = lrc;
     CVAE_TRY(launch_gemm_wide(false, gw, s));
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// nd projections + CE over the SAME targets (the decoder and the coupled decoder of a training step): one live-row
+// list, kept behind the FIRST decoder's saved logits; the backward pass takes it from there, zero-fills all
+// gradients in one launch and runs the decoders' products of one kind in one launch where they are small enough
+// to share the grid.  Saved-logits path only (logits[d] = ce_fast_logits_floats(N, V) floats each).
+int launch_ce_fast_forward_n(int nd, const float* const* X, const float* const* W, const float* const* bias,
+                             const int64_t* tgt, int64_t pad, long N, long TR, int E, int V, float* const* loss,
+                             float* const* lse, float* const* ws, float* const* logits, hipStream_t s) {
+  CVAE_REQUIRE(nd >= 1 && nd <= CeRowsOut::MAX, "ce_forward_n: %d decoders (max %d)", nd, CeRowsOut::MAX);
+  CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && N % TR == 0 && N < (1L << 31), "ce_forward_n: bad shape");
+  if (N == 0) return 0;
+  CVAE_REQUIRE(X && W && bias && tgt && loss && lse && ws && logits, "ce_forward_n: null operand");
+  const int cap = ce_cap(N, V);
+  int* rows = ce_saved_rows(logits[0], N, V);
+  int* nlive = rows + N;
+  CeArgs a[CeRowsOut::MAX] = {};
+  CeRowsOut o = {};
+  o.n = nd;
+  for (int d = 0; d < nd; ++d) {
+    CVAE_REQUIRE(X[d] && W[d] && bias[d] && loss[d] && lse[d] && ws[d] && logits[d] && aligned16(logits[d]),
+                 "ce_forward_n: null or misaligned operand");
+    float* tl = ws[d] + N + ce_counts_slots(N);
+    a[d].X = X[d]; a[d].W = W[d]; a[d].bias = bias[d]; a[d].tgt = tgt; a[d].rows = rows; a[d].nlive = nlive;
+    a[d].N = (int)N; a[d].TR = (int)TR; a[d].E = E; a[d].V = V;
+    a[d].vec = aligned16(X[d]) && aligned16(W[d]) && (E % 4 == 0);
+    a[d].cap = cap; a[d].pstride = N; a[d].tl = tl; a[d].pm = tl + N; a[d].ps = a[d].pm + (long)cap * N;
+    a[d].P = logits[d]; a[d].ldp = ce_ldp(V);
+    o.loss[d] = loss[d]; o.lse[d] = lse[d]; o.tl[d] = tl;
+  }
+  int* counts = reinterpret_cast<int*>(ws[0]) + N;
+  CVAE_TRY(launch_rows_n(tgt, pad, N, TR, rows, counts, nlive, o, s));
+  const long live = live_rows_for_profile(nlive, N, s);
+  for (int d = 0; d < nd; ++d) {
+    {
+      ProfScope prof(PK_CE_FWD, s, 2.0 * live * E * V);
+      CVAE_TRY((launch_core<false, true>(a[d], s, ws[d] + ce_fwd_base_floats(N, V))));
+    }
+    hipLaunchKernelGGL(ce_combine2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, a[d], persistent_grid_blocks(), loss[d], lse[d]);
+    CVAE_LAUNCH_CHECK("ce_combine2_kernel");
+  }
+  return 0;
+}
+
+int launch_ce_fast_backward_n(int nd, const float* const* X, const float* const* W, const float* const* bias,
+                              const int64_t* tgt, int64_t pad, const float* const* lse, const float* const* gsent,
+                              long N, long TR, int R, int E, int V, float* const* dX, float* const* dW,
+                              float* const* db, float* ws, float* const* logits, hipStream_t s) {
+  CVAE_REQUIRE(nd >= 1 && nd <= CeRowsOut::MAX && nd <= G224_MAX_BATCH, "ce_backward_n: %d decoders", nd);
+  CVAE_REQUIRE(ce_fast_supported(E) && V > 0 && TR > 0 && R > 0 && TR % R == 0 && N % TR == 0 && N < (1L << 31),
+               "ce_backward_n: bad shape");
+  CVAE_REQUIRE(X && W && bias && tgt && lse && gsent && dX && dW && db && ws && logits, "ce_backward_n: null operand");
+  ZeroBatch zb(s);
+  for (int d = 0; d < nd; ++d) {
+    CVAE_REQUIRE(X[d] && W[d] && bias[d] && lse[d] && gsent[d] && dX[d] && dW[d] && db[d] && logits[d] &&
+                 aligned16(logits[d]), "ce_backward_n: null or misaligned operand");
+    zb.add(dW[d], (long)V * E);
+    zb.add(db[d], V);
+    if (N) zb.add(dX[d], N * E);
+  }
+  CVAE_TRY(zb.flush());
+  if (N == 0) return 0;
+  int* rows = ce_saved_rows(logits[0], N, V);               // left there by launch_ce_fast_forward_n
+  int* nlive = rows + N;
+  const long ldp = ce_ldp(V);
+  const long live = live_rows_for_profile(nlive, N, s);
+  G224Args gx[G224_MAX_BATCH] = {}, gw[G224_MAX_BATCH] = {};
+  for (int d = 0; d < nd; ++d) {
+    CeArgs a = {};
+    a.X = X[d]; a.W = W[d]; a.bias = bias[d]; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
+    a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
+    a.vec = aligned16(X[d]) && aligned16(W[d]) && (E % 4 == 0);
+    a.cap = 64; a.lse = lse[d]; a.gsent = gsent[d]; a.R = R; a.P = logits[d]; a.ldp = ldp;
+    a.r0 = 0; a.rcount = (int)N;
+    const int nblk = (int)(N < 8192 ? N : 8192);
+    hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, a);
+    CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
+    // dX[rows[m], :] += P[m, :] . W
+    gx[d].A = logits[d]; gx[d].lda = ldp; gx[d].B = W[d]; gx[d].ldb = E; gx[d].C = dX[d]; gx[d].ldc = E;
+    gx[d].M = (int)N; gx[d].N = E; gx[d].K = V; gx[d].nlive = nlive; gx[d].r0 = 0; gx[d].dev_bound = 1; gx[d].rows = rows;
+    gx[d].prof_units = live;
+    // [dW | db] += P^T . [X[rows[k], :] | 1]
+    gw[d].A = logits[d]; gw[d].lda = ldp; gw[d].B = X[d]; gw[d].ldb = E; gw[d].C = dW[d]; gw[d].ldc = E;
+    gw[d].M = V; gw[d].N = E; gw[d].K = (int)N; gw[d].nlive = nlive; gw[d].r0 = 0; gw[d].dev_bound = 2; gw[d].rows = rows;
+    gw[d].extra = db[d]; gw[d].beta = 1; gw[d].prof_units = live;
+  }
+  // Products of one kind share a launch while every one of them still gets at least two k-ranges per tile on its share
+  // of the grid (the small batches, where a launch is a chain of round trips); big ones run one after the other on the
+  // whole grid (157 row tiles of a 20 000-word vocabulary on half of the grid would be one k-range each).
+  float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
+  const long share = persistent_grid_blocks() / nd;
+  auto run = [&](bool akc, G224Args* g, long tiles) -> int {
+    if (nd > 1 && share / tiles >= 2) return launch_gemm_wide_n(akc, g, nd, s);
+    for (int d = 0; d < nd; ++d) { g[d].part = part; CVAE_TRY(launch_gemm_wide(akc, g[d], s)); }
+    return 0;
+  };
+  CVAE_TRY(run(true, gx, cdiv(N, 128)));
+  CVAE_TRY(run(false, gw, cdiv(V, 128)));
   return 0;
 }
 

@@ -105,4 +105,13 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
                             const float* lse, const float* gsent, long N, long TR, int R, int E, int V,
                             float* dX, float* dW, float* db, float* ws, float* logits, hipStream_t s);
 
+// the same for nd decoders over one set of targets (saved-logits training path; the row list is built once)
+int launch_ce_fast_forward_n(int nd, const float* const* X, const float* const* W, const float* const* bias,
+                             const int64_t* tgt, int64_t pad, long N, long TR, int E, int V, float* const* loss,
+                             float* const* lse, float* const* ws, float* const* logits, hipStream_t s);
+int launch_ce_fast_backward_n(int nd, const float* const* X, const float* const* W, const float* const* bias,
+                              const int64_t* tgt, int64_t pad, const float* const* lse, const float* const* gsent,
+                              long N, long TR, int R, int E, int V, float* const* dX, float* const* dW,
+                              float* const* db, float* ws, float* const* logits, hipStream_t s);
+
 }  // namespace cvae

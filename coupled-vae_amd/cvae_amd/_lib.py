@@ -64,6 +64,9 @@ SIGNATURES = {
     'cvae_projce_logits_workspace': [L, L, L],
     'cvae_projce_forward_train': [P, P, P, P, L, I, I, I, I, L, P, P, P, P, P, P],
     'cvae_projce_backward_saved': [P, P, P, P, L, P, P, I, I, I, I, L, P, P, P, P, P, P],
+    'cvae_projce_forward_train_n': [I, P, P, P, P, L, I, I, I, L, P, P, P, P, P, P],
+    'cvae_projce_backward_saved_n_workspace': [L],
+    'cvae_projce_backward_saved_n': [I, P, P, P, P, L, P, P, I, I, I, L, P, P, P, P, P, P],
     'cvae_targets_time_major': [P, I, I, I, P, P],
     'cvae_logits': [P, P, P, I, I, I, L, P, P, P],
     'cvae_reparam_forward': [P, P, P, I, I, I, P, P],
@@ -85,7 +88,7 @@ SIGNATURES = {
     'cvae_axpy': [P, F, L, P, P],
 }
 _RESTYPE_LONG = {'cvae_encoder_backward_scratch', 'cvae_decoder_backward_scratch', 'cvae_projce_workspace',
-                 'cvae_decoder_greedy_scratch', 'cvae_projce_logits_workspace', 'cvae_decoder_beam_scratch',
+                 'cvae_decoder_greedy_scratch', 'cvae_projce_logits_workspace', 'cvae_projce_backward_saved_n_workspace', 'cvae_decoder_beam_scratch',
                  'cvae_projce_backward_workspace', 'cvae_mi_static_max_rows', 'cvae_stream_rnn_min_bytes'}
 
 for _name, _args in SIGNATURES.items():

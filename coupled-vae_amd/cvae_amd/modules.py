@@ -10,6 +10,8 @@ All arithmetic goes through libcvae_hip (ops.py).
 
 The greedy and beam branches of Decoder.forward are the step-wise entry points cvae_decoder_greedy / _beam.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -165,6 +167,7 @@ class LazyLogits(object):
         self.final, self.weight, self.bias, self.n_sent = final, weight, bias, n_sent
         self.order = order            # RowOrder the rows of `final` are in (None: the caller's order)
         self.shared = None            # dict shared with the sibling decoder's logits (decode_pair): targets built once
+        self.sibling, self.pair_index = None, 0    # the other decoder's logits of the same step (SeqLoss._paired)
         self.always_restore = False   # True: per-sentence sums go back to the caller's order whatever the settings say
 
     @property
@@ -229,12 +232,33 @@ class SeqLoss(nn.Module):
         tgt = gts[:logits.n_sent]
         if logits.order is not None:
             tgt = logits.order.targets(tgt)
-        sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad, cache=logits.shared)
+        sent = self._paired(logits, tgt)
+        if sent is None:
+            sent = ops.proj_ce(logits.final, logits.weight, logits.bias, tgt, self.pad, cache=logits.shared)
         if logits.order is not None:
             sent = sent.index_select(0, logits.order.res_idx) if logits.always_restore else logits.order.back(sent)
         if keep_batch:
             return sent
         return sent.sum() / (gts != self.pad).sum().to(sent.dtype)
+
+
+    def _paired(self, logits, tgt):
+        """The reference takes the decoder's and the coupled decoder's losses one after the other on the same targets
+        (Experiment.py:684-702).  The first of the two calls computes both (ops.proj_ce_pair), the second one finds
+        its result here; a sibling that is asked about other targets is computed on its own."""
+        sib = logits.sibling() if logits.sibling is not None else None
+        if sib is None or logits.shared is None:
+            return None
+        key = ('pair', tgt.data_ptr(), tuple(tgt.shape), tuple(tgt.stride()), tgt._version, int(self.pad))
+        hit = logits.shared.get(key)
+        if hit is None:
+            pair = (logits, sib) if logits.pair_index == 0 else (sib, logits)
+            if not ops.proj_ce_pair_ok([q.final for q in pair], [q.weight for q in pair]):
+                return None
+            outs = ops.proj_ce_pair([q.final for q in pair], [q.weight for q in pair], [q.bias for q in pair], tgt,
+                                    self.pad, cache=logits.shared)
+            hit = logits.shared[key] = (outs, tgt)          # holds tgt: its storage stays pinned while cached
+        return hit[0][logits.pair_index]
 
 
 # --------------------------------------------------------------------------- Encoder
@@ -389,6 +413,7 @@ def decode_pair(dec_a, dec_b, init_a, init_b, helper, order=None):
     la = LazyLogits(fa, dec_a.ToVocab.weight, dec_a.ToVocab.bias, B, order)
     lb = LazyLogits(fb, dec_b.ToVocab.weight, dec_b.ToVocab.bias, B, order)
     la.shared = lb.shared = {}
+    la.sibling, lb.sibling, lb.pair_index = weakref.ref(lb), weakref.ref(la), 1     # weak: no reference cycle
     return la, lb
 
 

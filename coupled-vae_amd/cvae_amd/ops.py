@@ -554,6 +554,83 @@ def proj_ce(final, W, b, eos, pad, cache=None):
     return ProjCEFn.apply(final, W, b, tgt, pad)
 
 
+class ProjCEPairFn(torch.autograd.Function):
+    """ProjCEFn for the nd decoders of a training step over ONE set of targets (cvae_projce_forward_train_n /
+    cvae_projce_backward_saved_n): inputs pad, tgt_tm, then (final, W, b) per decoder -> nd per-sentence sums."""
+
+    @staticmethod
+    def forward(ctx, pad, tgt_tm, *rest):
+        nd = len(rest) // 3
+        per = [[_c(t) for t in rest[3 * d:3 * d + 3]] for d in range(nd)]
+        T, R, E = per[0][0].shape
+        V = per[0][1].shape[0]
+        N = T * R
+        ref = per[0][0]
+        nws, nlog = query('cvae_projce_workspace', N, E, V), query('cvae_projce_logits_workspace', N, E, V)
+        loss_row, lse, sent = [[_f(shape, ref) for _ in range(nd)] for shape in ((N,), (N,), (R,))]
+        ws, logits = [_f((nws,), ref) for _ in range(nd)], [_f((nlog,), ref) for _ in range(nd)]
+        arrs = [ptr_array([per[d][k] for d in range(nd)]) for k in range(3)]
+        a_loss, a_lse, a_sent, a_ws, a_log = (ptr_array(x) for x in (loss_row, lse, sent, ws, logits))
+        call('cvae_projce_forward_train_n', nd, arrs[0], arrs[1], arrs[2], ptr(tgt_tm), pad, T, R, E, V, a_loss, a_lse,
+             a_sent, a_ws, a_log, stream())
+        ctx.pad, ctx.nd, ctx.logits = pad, nd, logits
+        ctx.save_for_backward(tgt_tm, *[t for d in range(nd) for t in per[d]], *lse)
+        return tuple(sent)
+
+    @staticmethod
+    def backward(ctx, *gsent):
+        nd = ctx.nd
+        sv = ctx.saved_tensors
+        tgt_tm, per, lse = sv[0], [sv[1 + 3 * d:4 + 3 * d] for d in range(nd)], sv[1 + 3 * nd:]
+        T, R, E = per[0][0].shape
+        V = per[0][1].shape[0]
+        g = [_c(gsent[d]) if gsent[d] is not None else torch.zeros((R,), dtype=torch.float32, device=tgt_tm.device)
+             for d in range(nd)]
+        grads = [[torch.empty_like(t) for t in per[d]] for d in range(nd)]
+        logits, ctx.logits = ctx.logits, None             # consumed (overwritten with the gradient)
+        if logits is None:                                # a second backward over a retained graph: recompute
+            ws = _f((query('cvae_projce_backward_workspace', T * R, E, V),), per[0][0])
+            for d in range(nd):
+                call('cvae_projce_backward', ptr(per[d][0]), ptr(per[d][1]), ptr(per[d][2]), ptr(tgt_tm), ctx.pad,
+                     ptr(lse[d]), ptr(g[d]), 1, T, R, E, V, ptr(grads[d][0]), ptr(grads[d][1]), ptr(grads[d][2]), ptr(ws),
+                     stream())
+            return (None, None) + tuple(t for d in range(nd) for t in grads[d])
+        ws = _f((query('cvae_projce_backward_saved_n_workspace', E),), per[0][0])
+        arrs = [ptr_array([per[d][k] for d in range(nd)]) for k in range(3)]
+        garr = [ptr_array([grads[d][k] for d in range(nd)]) for k in range(3)]
+        a_lse, a_g, a_log = ptr_array(list(lse)), ptr_array(g), ptr_array(logits)
+        call('cvae_projce_backward_saved_n', nd, arrs[0], arrs[1], arrs[2], ptr(tgt_tm), ctx.pad, a_lse, a_g, T, R, E, V,
+             garr[0], garr[1], garr[2], ptr(ws), a_log, stream())
+        return (None, None) + tuple(t for d in range(nd) for t in grads[d])
+
+
+def proj_ce_pair_ok(finals, Ws):
+    """The paired path covers a training step whose decoders have one shape and whose logits fit the save budget."""
+    if not (settings.ce_pair and settings.ce_save_logits and torch.is_grad_enabled()):
+        return False
+    T, R, E = finals[0].shape
+    V = Ws[0].shape[0]
+    if any(f.shape != finals[0].shape for f in finals) or any(w.shape != Ws[0].shape for w in Ws):
+        return False
+    n = query('cvae_projce_logits_workspace', T * R, E, V)
+    return 0 < n * 4 <= settings.ce_save_logits_max_bytes and T * R > 0
+
+
+def proj_ce_pair(finals, Ws, bs, eos, pad, cache=None):
+    """[final (T,R,E)] * nd, eos (B,T) -> nd per-sentence sums (R,), as nd proj_ce calls."""
+    R = finals[0].shape[1]
+    if cache is None:
+        tgt = targets_time_major(eos, R)
+    else:
+        key = ('tgt_tm', eos.data_ptr(), tuple(eos.shape), tuple(eos.stride()), eos._version, R)
+        hit = cache.get(key)
+        if hit is None:
+            hit = cache[key] = (targets_time_major(eos, R), eos)
+        tgt = hit[0]
+    flat = [t for d in range(len(finals)) for t in (finals[d], Ws[d], bs[d])]
+    return ProjCEPairFn.apply(pad, tgt, *flat)
+
+
 def proj_ce_sorted(final, W, b, eos, pad):
     """final (T,B*K,E) on sentence-major rows, eos (B,T) -> (B*K,)."""
     B = eos.shape[0]

@@ -10,6 +10,8 @@ class _Settings(object):
     pair_encoders = True      # dialogue model: post and response encoders in the same launches (ops.encoder_pair)
     ce_save_logits = True     # training: keep the live rows' logits from the CE forward for its backward (no recompute)
     ce_save_logits_max_bytes = 8 << 30   # per call; above it the backward recomputes
+    ce_pair = True            # training: the decoder's and the coupled decoder's losses over the same targets share
+    #                           one row scan, one zero-fill and (small batches) their gradient products' launches
     shard_samples = False     # multi-GPU IW eval: shard the K samples of every sentence over ranks (dist_utils)
     truncate_eval = True      # cut T to max(len)+1 in test_lm (exact: pad targets weigh 0)
     sort_train_rows = True    # training forward: process the batch's rows in order of non-increasing length

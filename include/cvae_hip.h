@@ -219,6 +219,22 @@ int cvae_projce_forward_train(const float* final, const float* W, const float* b
 int cvae_projce_backward_saved(const float* final, const float* W, const float* b, const int64_t* tgt, int64_t pad,
                                const float* lse, const float* gsent, int nseg, int T, int R, int E, int64_t V,
                                float* dfinal, float* dW, float* db, float* ws, float* logits, void* stream);
+/* The same pair for nd <= 4 decoders of identical shape over ONE set of targets -- Decoder and DecoderCouple of a
+ * training step, whose losses the reference takes one after the other on the same `eos`
+ * (Coupled-VAE/Experiment.py:684-702; Modules/Losses/SeqLoss.py).  Arguments are arrays of nd pointers (ws[d]:
+ * cvae_projce_workspace(T*R, E, V) floats each; logits[d]: cvae_projce_logits_workspace floats each).  The live-row
+ * list is built once and kept behind logits[0] for the backward call, which zero-fills every gradient in one launch
+ * and runs the decoders' products of one kind in one launch where they are small enough to share the grid
+ * (ws there: cvae_projce_backward_saved_n_workspace(E) floats, shared).  Results equal nd separate calls'. */
+int cvae_projce_forward_train_n(int nd, const float* const* final, const float* const* W, const float* const* b,
+                                const int64_t* tgt, int64_t pad, int T, int R, int E, int64_t V,
+                                float* const* loss_row, float* const* lse, float* const* sent, float* const* ws,
+                                float* const* logits, void* stream);
+int64_t cvae_projce_backward_saved_n_workspace(int64_t E);
+int cvae_projce_backward_saved_n(int nd, const float* const* final, const float* const* W, const float* const* b,
+                                 const int64_t* tgt, int64_t pad, const float* const* lse, const float* const* gsent,
+                                 int T, int R, int E, int64_t V, float* const* dfinal, float* const* dW,
+                                 float* const* db, float* ws, float* const* logits, void* stream);
 /* tgt_tm[t*R + r] = eos[(r % B)*T + t]: time-major targets for R = n*B rows. */
 int cvae_targets_time_major(const int64_t* eos, int B, int T, int R, int64_t* tgt_tm, void* stream);
 /* tgt_tm[t*B*K + r] = eos[(r / K)*T + t]: the same for sentence-major rows r = b*K + k. */

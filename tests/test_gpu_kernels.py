@@ -386,6 +386,54 @@ def test_projce_forward_backward(dev, shape):
     assert rel(lg, O.decoder_logits(P, 'D.', f64)) < 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(9, 5, 16, 50), (30, 32, 200, 2100), (41, 32, 200, 10002), (64, 32, 200, 20000)])
+def test_projce_pair_matches_oracle_and_single(dev, shape):
+    """The two decoders' losses over one set of targets in one call (cvae_projce_forward_train_n /
+    cvae_projce_backward_saved_n: shared row list, one zero-fill, batched gradient products where they are small):
+    against the fp64 oracle and against two separate calls; only one of the two losses carrying a gradient too."""
+    from cvae_amd import ops
+    T, R, E, V = shape
+    g = torch.Generator().manual_seed(11)
+    finals = [torch.tanh(torch.randn(T, R, E, generator=g)) for _ in range(2)]
+    Ws = [torch.randn(V, E, generator=g) * 0.1 for _ in range(2)]
+    bs = [torch.randn(V, generator=g) * 0.1 for _ in range(2)]
+    eos = torch.randint(1, V, (R, T), generator=g)
+    for r in range(R):                                   # ragged targets, one all-pad sentence
+        eos[r, max(1, T - r):] = 0
+    eos[R - 1, :] = 0
+    gs = [torch.randn(R, generator=g) for _ in range(2)]
+    refs = []
+    for d in range(2):
+        f64 = finals[d].double().requires_grad_(True)
+        P = {'D.ToVocab.weight': Ws[d].double().requires_grad_(True), 'D.ToVocab.bias': bs[d].double().requires_grad_(True)}
+        out = O.seq_xent(P, 'D.', f64, eos)
+        (out * gs[d].double()).sum().backward()
+        refs.append((out, f64.grad, P['D.ToVocab.weight'].grad, P['D.ToVocab.bias'].grad))
+    dv = [[t.to(dev).requires_grad_(True) for t in (finals[d], Ws[d], bs[d])] for d in range(2)]
+    assert ops.proj_ce_pair_ok([dv[0][0], dv[1][0]], [dv[0][1], dv[1][1]])
+    outs = ops.proj_ce_pair([dv[0][0], dv[1][0]], [dv[0][1], dv[1][1]], [dv[0][2], dv[1][2]], eos.to(dev), 0)
+    sum((outs[d] * gs[d].to(dev)).sum() for d in range(2)).backward()
+    for d in range(2):
+        assert rel(outs[d], refs[d][0]) < 2e-5
+        for got, want in zip([t.grad for t in dv[d]], refs[d][1:]):
+            assert rel(got, want) < 1e-4
+        # two separate calls
+        sv = [t.detach().clone().requires_grad_(True) for t in dv[d]]
+        single = ops.proj_ce(sv[0], sv[1], sv[2], eos.to(dev), 0)
+        (single * gs[d].to(dev)).sum().backward()
+        assert torch.equal(single, outs[d])
+        for got, want in zip([t.grad for t in dv[d]], [t.grad for t in sv]):
+            assert rel(got, want) < 2e-6
+    # only the second loss is used: the first one's gradients are exactly zero, the second one's unchanged
+    dv2 = [[t.detach().clone().requires_grad_(True) for t in dv[d]] for d in range(2)]
+    outs2 = ops.proj_ce_pair([dv2[0][0], dv2[1][0]], [dv2[0][1], dv2[1][1]], [dv2[0][2], dv2[1][2]], eos.to(dev), 0)
+    (outs2[1] * gs[1].to(dev)).sum().backward()
+    assert all(float(t.grad.abs().max()) == 0.0 for t in dv2[0])
+    for got, want in zip([t.grad for t in dv2[1]], [t.grad for t in dv[1]]):
+        assert rel(got, want) < 2e-6
+
+
 def test_latent_kernels(dev):
     from cvae_amd import ops
     g = torch.Generator().manual_seed(7)
