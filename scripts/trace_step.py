@@ -14,3 +14,12 @@ for i, r in enumerate(rows[a:b]):
     busy += (e - s) / 1e3; gap += max(0, s - prev) / 1e3
     prev = max(prev, e)
 print('launches %d  busy %.1f us  gaps %.1f us' % (b - a, busy, gap))
+agg = {}
+for r in rows[a:b]:
+    name = r['Kernel_Name'].replace('cvae::', '').replace('void ', '').split('(')[0][:60]
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    n, t = agg.get(name, (0, 0.0))
+    agg[name] = (n + 1, t + d)
+print('--- by kernel')
+for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print('%4d x %9.1f us  %s' % (n, t, name))
