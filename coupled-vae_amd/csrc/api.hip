@@ -61,6 +61,17 @@ int split_bf16_set(int on) {
   return prev;
 }
 
+static int g_deterministic = -1;                 // -1: not set yet (env CVAE_DETERMINISTIC, default off)
+bool deterministic_enabled() {
+  if (g_deterministic < 0) { const char* e = getenv("CVAE_DETERMINISTIC"); g_deterministic = (e && e[0] == '1') ? 1 : 0; }
+  return g_deterministic != 0;
+}
+int deterministic_set(int on) {
+  const int prev = deterministic_enabled() ? 1 : 0;
+  g_deterministic = on ? 1 : 0;
+  return prev;
+}
+
 ProfScope::ProfScope(int kernel, hipStream_t stream, double work) : slot(-1), s(stream) {
   if (!g_prof_on || g_prof.size() >= kProfMaxRecs) return;
   ProfRec r;
@@ -357,7 +368,7 @@ struct EncBwd {
   float* const* dw; float* scratch;
 };
 static int encoder_backward_impl(int ne, int cell, int B, int L, int E, int H, const EncBwd* ee, float* demb,
-                                 hipStream_t s) {
+                                 hipStream_t s, long V) {
   CVAE_REQUIRE(ne >= 1 && 2 * ne <= SKINNY_MAX_BATCH, "encoder_backward: %d encoders (max %d)", ne, SKINNY_MAX_BATCH / 2);
   const int G = gates_of(cell);
   const long LBG = (long)L * B * G * H, BH = (long)B * H;
@@ -436,7 +447,7 @@ static int encoder_backward_impl(int ne, int cell, int B, int L, int E, int H, c
     CVAE_TRY(launch_gemm_n(gd, ne, s));
   }
   for (int e = 0; e < ne; ++e)
-    CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ee[e].ids, dX[e], ee[e].mask, ee[e].mask_rows, demb, s));
+    CVAE_TRY(launch_embed_scatter(L, B, E, E, 0, ee[e].ids, dX[e], ee[e].mask, ee[e].mask_rows, demb, s, V));
   return 0;
 }
 
@@ -448,7 +459,7 @@ int cvae_encoder_backward(int cell, int B, int L, int E, int H, int64_t V, const
   CVAE_REQUIRE(B > 0 && L > 0 && E > 0 && H > 0 && V > 0, "encoder_backward: bad shape");
   CVAE_REQUIRE(demb, "encoder_backward: null operand");
   EncBwd q = {ids, len, mask, mask_rows, w, X, hs, cs, gates, dlast, dw, scratch};
-  return encoder_backward_impl(1, cell, B, L, E, H, &q, demb, S(stream));
+  return encoder_backward_impl(1, cell, B, L, E, H, &q, demb, S(stream), (long)V);
 }
 
 int cvae_encoder_backward_n(int ne, int cell, int B, int L, int E, int H, int64_t V, const int64_t* const* ids,
@@ -465,7 +476,7 @@ int cvae_encoder_backward_n(int ne, int cell, int B, int L, int E, int H, int64_
   for (int e = 0; e < ne; ++e)
     q[e] = EncBwd{ids[e], len[e], mask[e], mask_rows[e], w + 8 * e, X[e], hs[e], cs[e], gates[e], dlast[e],
                   dw + 8 * e, scratch[e]};
-  return encoder_backward_impl(ne, cell, B, L, E, H, q, demb, S(stream));
+  return encoder_backward_impl(ne, cell, B, L, E, H, q, demb, S(stream), (long)V);
 }
 
 // ------------------------------------------------------------------------------ decoder
@@ -778,7 +789,7 @@ struct DecBwd {
 };
 
 static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, const int64_t* go,
-                                 const DecBwd* dd, float* demb, hipStream_t s, int skip_prefix = 0) {
+                                 const DecBwd* dd, float* demb, hipStream_t s, long V, int skip_prefix = 0) {
   CVAE_REQUIRE(nd >= 1 && nd <= SKINNY_MAX_BATCH, "decoder_backward: %d decoders (max %d)", nd, SKINNY_MAX_BATCH);
   const int G = gates_of(cell), T1 = T + 1;
   const long BH = (long)B * Hd, GH = (long)G * Hd;
@@ -888,7 +899,7 @@ static int decoder_backward_impl(int nd, int cell, int B, int T, int E, int Hd, 
   CVAE_TRY(launch_gemm_n(gd, nd, s));
   for (int d = 0; d < nd; ++d) {
     CVAE_TRY(launch_dec_dinit(T, B, E, dX[d], dd[d].mask_in, dd[d].dinit, s));
-    CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], dd[d].mask_in, nullptr, demb, s));
+    CVAE_TRY(launch_embed_scatter(T, B, E, 2 * E, 1, go, dX[d], dd[d].mask_in, nullptr, demb, s, V));
   }
   return 0;
 }
@@ -902,7 +913,7 @@ int cvae_decoder_backward(int cell, int B, int T, int E, int Hd, int64_t V, cons
   CVAE_REQUIRE(B > 0 && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward: bad shape");
   CVAE_REQUIRE(go && demb, "decoder_backward: null operand");
   DecBwd q = {mask_in, mask_out, w, X, hs, cs, gates, hdrop, final, dfinal, dinit, dw, scratch};
-  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream));
+  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream), (long)V);
 }
 
 // LM decoder (CV/Modules/lm.py:78-100): the training branch without the prefix step (h_0 = 0).  The caller
@@ -926,7 +937,7 @@ int cvae_decoder_backward_noprefix(int cell, int B, int T, int E, int Hd, int64_
   CVAE_REQUIRE(B > 0 && T > 0 && E > 0 && Hd > 0 && V > 0, "decoder_backward_noprefix: bad shape");
   CVAE_REQUIRE(go && demb, "decoder_backward_noprefix: null operand");
   DecBwd q = {mask_in, mask_out, w, X, hs, cs, gates, hdrop, final, dfinal, dinit, dw, scratch};
-  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream), 1);
+  return decoder_backward_impl(1, cell, B, T, E, Hd, go, &q, demb, S(stream), (long)V, 1);
 }
 
 int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64_t V, const int64_t* go,
@@ -945,7 +956,7 @@ int cvae_decoder_backward_n(int nd, int cell, int B, int T, int E, int Hd, int64
     q[d] = {mask_in ? mask_in[d] : nullptr, mask_out ? mask_out[d] : nullptr, w + 6 * d, X[d], hs[d],
             cs ? cs[d] : nullptr, gates[d], hdrop ? hdrop[d] : nullptr, final[d], dfinal[d], dinit[d], dw + 6 * d,
             scratch[d]};
-  return decoder_backward_impl(nd, cell, B, T, E, Hd, go, q, demb, S(stream));
+  return decoder_backward_impl(nd, cell, B, T, E, Hd, go, q, demb, S(stream), (long)V);
 }
 
 // ------------------------------------------------------------------------------ projection + CE
@@ -1023,6 +1034,7 @@ int cvae_projce_backward_saved_n(int nd, const float* const* final, const float*
 }
 
 int cvae_split_bf16(int on) { return split_bf16_set(on); }
+int cvae_deterministic(int on) { return deterministic_set(on); }
 int64_t cvae_stream_rnn_min_bytes(int64_t bytes) { return stream_rnn_min_weight_bytes(bytes); }
 
 int64_t cvae_projce_backward_workspace(int64_t N, int64_t E, int64_t V) {

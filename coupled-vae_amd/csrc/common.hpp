@@ -48,13 +48,18 @@ bool prof_enabled();   // true while cvae_profile_enable(1) is in effect
 // or cvae_split_bf16(0) selects the fp32-input MFMA kernels instead.
 bool split_bf16_enabled();
 int split_bf16_set(int on);      // returns the previous setting
+// Run-to-run bit-reproducible results (cvae_deterministic / CVAE_DETERMINISTIC=1, default off): the three places that
+// add floats with atomics take an order-independent path instead (embedding-gradient scatter through 64-bit fixed
+// point, no atomic split-K in gemm_tiled, column sums in one block per column group).
+bool deterministic_enabled();
+int deterministic_set(int on);   // returns the previous setting
 
 // ---- library-owned device scratch (api.hip): one buffer per (kind, device, stream), so launches on different
 // streams (or host threads driving different streams) never share flag words, exchange slabs or index lists.
 // Allocated at first use and regrown only when a larger shape arrives (warm-up; hipFree of the old buffer
 // synchronises the device); steady-state calls allocate nothing.  Guarded by a mutex.
 enum LibScratchKind { LS_PERSIST_SYNC = 0, LS_PERSIST_EXCH = 1, LS_WIDE_PART = 2, LS_ROWS = 3, LS_STREAM_IMG = 4,
-                      LS_STREAM_PARTS = 5, LS_KINDS = 6 };
+                      LS_STREAM_PARTS = 5, LS_SUMSQ = 6, LS_EMB_FIX = 7, LS_KINDS = 8 };
 // zero != 0: a new buffer is zero-filled (synchronously) before it is handed out.  fresh (optional): set when
 // this call (re)allocated.
 int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero = 0, bool* fresh = nullptr);

@@ -436,7 +436,7 @@ static int launch_tiled(const GemmDesc& d, hipStream_t s) {
   // split-K when the output has too few tiles to fill 256 CUs and K is long
   const long tiles = (long)cdiv(d.N, BN) * cdiv(d.M, BM);
   int ksplit = 1;
-  if (d.act == ACT_NONE && tiles < 128 && d.K >= 1024) {
+  if (d.act == ACT_NONE && tiles < 128 && d.K >= 1024 && !deterministic_enabled()) {     // (atomic accumulation)
     ksplit = (int)((512 + tiles - 1) / tiles);
     const int maxs = d.K / 256;
     if (ksplit > maxs) ksplit = maxs;

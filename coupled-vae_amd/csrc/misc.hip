@@ -124,9 +124,52 @@ __global__ void embed_scatter_kernel(int T, int B, int E, int W, int slot0, cons
   if (v != 0.f) atomicAdd(demb + ids[(long)b * T + t] * E + e, v);   // padded steps / dropped elements: exact zeros
 }
 
+// Deterministic form: the same sums through 64-bit fixed point (2^-36 units; integer adds commute, so the order in
+// which the atomics land does not matter), then demb += fix * 2^-36 in one pass.  Resolution 1.5e-11, range +-1.3e8
+// per element; entries outside +-1e6 (never seen in a gradient that passes the clip) are clamped.
+constexpr double EMB_FIX_SCALE = 68719476736.0;   // 2^36
+__global__ void embed_scatter_fix_kernel(int T, int B, int E, int W, int slot0, const int64_t* __restrict__ ids,
+                                         const float* __restrict__ dX, const float* __restrict__ mask,
+                                         const int64_t* __restrict__ mask_rows, unsigned long long* __restrict__ fix) {
+  IDX1D((long)T * B * E);
+  const int e = (int)(idx % E);
+  const int b = (int)((idx / E) % B);
+  const int t = (int)(idx / ((long)E * B));
+  float v = dX[((long)(t + slot0) * B + b) * W + e];
+  if (mask) {
+    const long mr = mask_rows ? mask_rows[b] : b;
+    v *= mask[((long)t * B + mr) * W + e];
+  }
+  if (v != 0.f) {
+    const double c = fmin(fmax((double)v, -1.0e6), 1.0e6);
+    const long long q = __double2ll_rn(c * EMB_FIX_SCALE);
+    atomicAdd(fix + ids[(long)b * T + t] * E + e, (unsigned long long)q);       // two's complement: wraps like a signed add
+  }
+}
+__global__ void embed_fix_apply_kernel(long n, unsigned long long* __restrict__ fix, float* __restrict__ demb) {
+  IDX1D(n);
+  const long long q = (long long)fix[idx];
+  if (q != 0) {
+    demb[idx] += (float)((double)q * (1.0 / EMB_FIX_SCALE));
+    fix[idx] = 0ull;                                 // the buffer is all zero again for the next call
+  }
+}
+
 int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* ids, const float* dX,
-                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s) {
+                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s, long V) {
   if ((long)T * B * E == 0) return 0;
+  if (deterministic_enabled() && V > 0) {
+    void* buf = nullptr;
+    bool fresh = false;
+    CVAE_TRY(lib_scratch(LS_EMB_FIX, s, (size_t)V * E * sizeof(unsigned long long), &buf, 1, &fresh));
+    unsigned long long* fix = static_cast<unsigned long long*>(buf);
+    hipLaunchKernelGGL(embed_scatter_fix_kernel, GRID1D((long)T * B * E), 0, s, T, B, E, W, slot0, ids, dX, mask,
+                       mask_rows, fix);
+    CVAE_LAUNCH_CHECK("embed_scatter_fix_kernel");
+    hipLaunchKernelGGL(embed_fix_apply_kernel, GRID1D((long)V * E), 0, s, (long)V * E, fix, demb);
+    CVAE_LAUNCH_CHECK("embed_fix_apply_kernel");
+    return 0;
+  }
   hipLaunchKernelGGL(embed_scatter_kernel, GRID1D((long)T * B * E), 0, s, T, B, E, W, slot0, ids, dX, mask,
                      mask_rows, demb);
   CVAE_LAUNCH_CHECK("embed_scatter_kernel");
@@ -1209,7 +1252,9 @@ int launch_mi_static(const float* z, const float* mu, const float* sigma, int K,
 }
 
 // ------------------------------------------------------------------ clip + Adam (a12)
-// sumsq[0] = sum over all grads^2, sumsq[1] = sum over the alias segment
+// out[b] = block b's sum over all grads^2, out[SUMSQ_MAX_BLOCKS + b] = its sum over the alias segment.  No float
+// atomics: the clip norm is the same bits on every run (and on every rank of a data-parallel job).
+constexpr int SUMSQ_MAX_BLOCKS = 256;
 __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
                                                      float* __restrict__ out, const int* __restrict__ status_in,
                                                      int* __restrict__ status_copy) {
@@ -1228,12 +1273,12 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = all; red[1][wave] = al; }
   __syncthreads();
-  if (threadIdx.x == 0) {           // same-address float atomics cost ~12 ns each: one pair per block
+  if (threadIdx.x == 0) {           // one pair of partial sums per block; clip_adam_kernel adds them in a fixed order
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
-    atomicAdd(out, s0);
-    if (s1 != 0.f) atomicAdd(out + 1, s1);
+    out[blockIdx.x] = s0;
+    out[SUMSQ_MAX_BLOCKS + blockIdx.x] = s1;
   }
 }
 
@@ -1241,14 +1286,31 @@ struct AdamSteps { float step_size[8]; float bc2_sqrt[8]; };   // per listing: l
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1, int mult, float max_norm,
                                                         float b1, float b2, float eps, AdamSteps other,
-                                                        AdamSteps alias_steps, const float* __restrict__ sumsq,
+                                                        AdamSteps alias_steps, const float* __restrict__ parts,
+                                                        int nparts, float* __restrict__ sumsq,
                                                         float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ norm_out,
                                                         const int* __restrict__ status_copy) {
   if (status_copy && *status_copy) return;            // invalid gradients (a recurrent kernel timed out): no step
+  // the blocks' partial sums, added by every block in the same order (4 per lane, then a fixed butterfly)
+  __shared__ float tot[2];
+  if (threadIdx.x < 64) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < SUMSQ_MAX_BLOCKS / 64; ++j) {
+      const int b = threadIdx.x + 64 * j;
+      if (b < nparts) { s0 += parts[b]; s1 += parts[SUMSQ_MAX_BLOCKS + b]; }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (threadIdx.x == 0) {
+      tot[0] = s0; tot[1] = s1;
+      if (blockIdx.x == 0) { sumsq[0] = s0; sumsq[1] = s1; }
+    }
+  }
+  __syncthreads();
   // total norm as clip_grad_norm_ sees it: the aliased segment is listed `mult` times
-  const float total = sqrtf(sumsq[0] + (float)(mult - 1) * sumsq[1]);
+  const float total = sqrtf(tot[0] + (float)(mult - 1) * tot[1]);
   float coef = max_norm / (total + 1e-6f);
   coef = coef > 1.f ? 1.f : coef;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1285,14 +1347,16 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
                "clip_adam: bad segment (alias_mult must be 1..8)");
   if (n == 0) return 0;
   CVAE_REQUIRE(p && g && m && v && sumsq, "clip_adam: null operand");
-  CVAE_TRY(launch_zero(sumsq, 2, s));
+  void* partbuf = nullptr;
+  CVAE_TRY(lib_scratch(LS_SUMSQ, s, 2 * SUMSQ_MAX_BLOCKS * sizeof(float), &partbuf));
+  float* parts = static_cast<float*>(partbuf);
   int grid = cdiv(n, 256 * 8);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   int sgrid = cdiv(n, 1024 * 8);
-  if (sgrid > 256) sgrid = 256;
+  if (sgrid > SUMSQ_MAX_BLOCKS) sgrid = SUMSQ_MAX_BLOCKS;
   if (sgrid < 1) sgrid = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, sumsq,
+  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, parts,
                      status_in, status_copy);
   CVAE_LAUNCH_CHECK("sumsq_kernel");
   AdamSteps so = {}, sa = {};
@@ -1303,7 +1367,7 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
     sa.bc2_sqrt[r] = (float)sqrt(1.0 - pow((double)b2, (double)(step_alias + 1 + r)));
   }
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, mult,
-                     max_norm, b1, b2, eps, so, sa, sumsq, p, g, m, v, norm_out, status_copy);
+                     max_norm, b1, b2, eps, so, sa, parts, sgrid, sumsq, p, g, m, v, norm_out, status_copy);
   CVAE_LAUNCH_CHECK("clip_adam_kernel");
   return 0;
 }

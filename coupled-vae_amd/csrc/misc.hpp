@@ -10,8 +10,9 @@ int launch_pack_batch(const int64_t* flat, const int64_t* off, const int64_t* se
 int launch_sort_resort(const int64_t* len, int B, int64_t* s_idx, int64_t* res_idx, hipStream_t s);
 int launch_embed(int T, int R, int E, int with_cond, int prefix, const int64_t* ids, int Bids, const float* emb,
                  const float* cond, const float* mask, const int64_t* mask_rows, float* out, hipStream_t s);
+// V: rows of demb (only the deterministic form needs it; 0 = unknown -> float atomics)
 int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* ids, const float* dX,
-                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s);
+                         const float* mask, const int64_t* mask_rows, float* demb, hipStream_t s, long V = 0);
 int launch_dec_dinit(int T, int B, int E, const float* dX, const float* mask, float* dinit, hipStream_t s);
 int launch_mul(long n, const float* a, const float* b, float* o, hipStream_t s);
 int launch_act_bwd(long n, int act, const float* y, const float* dy, float* o, hipStream_t s);

@@ -220,6 +220,7 @@ int launch_colsum_acc(const float* P, int M, int N, long ld, float* out, hipStre
   if (M == 0 || N == 0) return 0;
   int rpb = 64;
   if ((long)cdiv(N, 256) * cdiv(M, rpb) > 4096) rpb = cdiv(M, cdiv(4096, cdiv(N, 256)));
+  if (deterministic_enabled()) rpb = M;          // one block per column group: one atomic per output, no order to vary
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, s, M, N, P, ld, out, rpb);
   CVAE_LAUNCH_CHECK("colsum_kernel");
   return 0;

@@ -310,7 +310,9 @@ int cvae_mi_static(const float* z, const float* mu, const float* sigma, int K, i
  * times: its squared norm counts that many times, its gradient is scaled by coef^mult and it
  * takes `alias_mult` Adam steps per call (step counter kept by the caller: step_other for
  * the rest, step_alias = value BEFORE this call for the alias segment).
- * sumsq: 2 floats of device scratch.  params/grads/m/v: n floats each. */
+ * sumsq: 2 floats that receive the squared norms (all gradients, alias segment); they are summed without float
+ * atomics, block partials in a fixed order: the clip coefficient is bit-identical from run to run.
+ * params/grads/m/v: n floats each. */
 int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
                    int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
                    float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
@@ -331,6 +333,13 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
  * fp32-input MFMA kernels (v_mfma_f32_32x32x2_f32) everywhere; returns the previous setting; env CVAE_SPLIT_BF16=0
  * sets the default. */
 int cvae_split_bf16(int on);
+/* Run-to-run bit-reproducible results (no counterpart in the reference; default off, env CVAE_DETERMINISTIC=1):
+ * the three places that add floats with atomics take an order-independent path -- the embedding-gradient scatter of
+ * cvae_encoder_backward* / cvae_decoder_backward* goes through 64-bit fixed point (2^-36 units; library-owned
+ * V*E*8-byte buffer per stream), cvae_gemm's small-output products are not split over K, column sums run in one
+ * block per column group.  Everything else (split-K slabs, recurrent exchanges, the clip norm) adds in a fixed
+ * order in either mode.  Returns the previous setting. */
+int cvae_deterministic(int on);
 /* Recurrent layers whose W_hh is far larger than the chip's L2 (R <= 64 rows, H % 64 == 0, split-bf16 on; the scale-up
  * shape: 67 MB per 2048-unit LSTM) run their per-step kernels in a weight-streaming form: W_hh pre-split once per
  * sequence into a fragment-ordered bf16 hi / lo image, bf16x3 products, fused cell (forward) / K-split partial

@@ -192,3 +192,36 @@ def test_persist_timeout_is_loud_and_the_step_is_not_applied(dev):
     tr.train_step(batch)
     torch.cuda.synchronize()
     assert not torch.equal(tr.opt.params, before)
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_is_bit_reproducible(dev):
+    """cvae_deterministic(1): three training steps from the same seed give bit-identical parameters, losses and clip
+    norms on two runs (the embedding-gradient scatter, the only float-atomic accumulation of a training step, goes
+    through fixed point), and agree with the default mode to fp32 rounding.  PTB shape, vocabulary cut to 600 so that
+    tokens repeat many times within a batch."""
+    from cvae_amd import data, harness, _lib
+    s = data.SHAPES['ptb']
+    hp = harness.HParams(model='vae-couple', cell='lstm', V=600, E=s['E'], H=s['H'], Z=s['Z'], batch_size=32)
+    c = data.Corpus(data.synthetic_sentences(96, 600, s['mu'], s['sigma'], s['cap'], seed=41))
+
+    def run():
+        tr = harness.Trainer(hp, dev, seed=9)
+        torch.manual_seed(123)
+        out = []
+        for i in range(3):
+            res = tr.train_step(harness.text_batch(c, range(32 * i, 32 * i + 32), dev))
+            out.append((float(res['tot']), float(tr.opt.norm)))
+        return out, tr.opt.params.detach().cpu().clone()
+
+    prev = _lib.query('cvae_deterministic', 1)
+    try:
+        a, pa = run()
+        b, pb = run()
+        assert a == b and torch.equal(pa, pb)
+        _lib.query('cvae_deterministic', 0)
+        d, pd = run()
+    finally:
+        _lib.query('cvae_deterministic', prev)
+    assert all(abs(x[0] - y[0]) < 1e-5 * abs(y[0]) for x, y in zip(a, d))
+    assert float((pa - pd).abs().max()) < 1e-5

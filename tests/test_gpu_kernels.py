@@ -516,6 +516,7 @@ def test_clip_adam_alias_semantics(dev):
         for step in range(3):
             gr = torch.randn(n_emb + n_rest, generator=g) * scale
             ge = gr[:n_emb].clone()
+            want_sq = (float((gr.double() ** 2).sum()), float((ge.double() ** 2).sum()))   # the oracle scales in place
             grads = {'A.Embedding.weight': ge, 'B.Embedding.weight': ge, 'C.Embedding.weight': ge,
                      'rest': gr[n_emb:].clone()}
             total = O.clip_and_adam(P, grads, state, keys)
@@ -524,6 +525,18 @@ def test_clip_adam_alias_semantics(dev):
             assert abs(float(norm) - total) < 1e-4 * total
             ref = torch.cat([P['A.Embedding.weight'], P['rest']])
             assert float((pd.cpu() - ref).abs().max()) < 2e-6, (scale, step)
+            # sumsq receives the two squared norms (all gradients, alias segment)
+            assert abs(float(sumsq[0]) - want_sq[0]) < 1e-5 * want_sq[0]
+            assert abs(float(sumsq[1]) - want_sq[1]) < 1e-5 * want_sq[1]
+    # the norm is summed without float atomics: the same bits on every run, at a size that takes every block
+    big = torch.randn(3_000_000, generator=g).to(dev)
+    outs = []
+    for _ in range(4):
+        pd, m, v = torch.zeros_like(big), torch.zeros_like(big), torch.zeros_like(big)
+        ops.clip_adam(pd, big.clone(), m, v, 0, 100_000, 2, 5.0, 1e-3, (0.9, 0.999), 1e-8, 0, 0, sumsq, norm)
+        outs.append((float(norm), sumsq.cpu().clone(), pd.cpu()))
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
 def test_kl_free_bits(dev):
