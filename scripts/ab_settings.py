@@ -1,4 +1,4 @@
-"""Diagnostic A/B of cvae_amd.settings flags on the training step: python scripts/_ab.py flag=value ... (SHAPE env)."""
+"""Diagnostic A/B of cvae_amd.settings flags on the training step: python scripts/ab_settings.py flag=value ... (SHAPE env)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'coupled-vae_amd'))
