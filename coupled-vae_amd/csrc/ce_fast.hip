@@ -912,16 +912,14 @@ int launch_ce_fast_backward_n(int nd, const float* const* X, const float* const*
   const long ldp = ce_ldp(V);
   const long live = live_rows_for_profile(nlive, N, s);
   G224Args gx[G224_MAX_BATCH] = {}, gw[G224_MAX_BATCH] = {};
+  CeArgs ga[G224_MAX_BATCH] = {};
   for (int d = 0; d < nd; ++d) {
-    CeArgs a = {};
+    CeArgs& a = ga[d];
     a.X = X[d]; a.W = W[d]; a.bias = bias[d]; a.tgt = tgt; a.rows = rows; a.nlive = nlive;
     a.N = (int)N; a.TR = (int)TR; a.E = E; a.V = V;
     a.vec = aligned16(X[d]) && aligned16(W[d]) && (E % 4 == 0);
     a.cap = 64; a.lse = lse[d]; a.gsent = gsent[d]; a.R = R; a.P = logits[d]; a.ldp = ldp;
     a.r0 = 0; a.rcount = (int)N;
-    const int nblk = (int)(N < 8192 ? N : 8192);
-    hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, a);
-    CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
     // dX[rows[m], :] += P[m, :] . W
     gx[d].A = logits[d]; gx[d].lda = ldp; gx[d].B = W[d]; gx[d].ldb = E; gx[d].C = dX[d]; gx[d].ldc = E;
     gx[d].M = (int)N; gx[d].N = E; gx[d].K = V; gx[d].nlive = nlive; gx[d].r0 = 0; gx[d].dev_bound = 1; gx[d].rows = rows;
@@ -931,18 +929,36 @@ int launch_ce_fast_backward_n(int nd, const float* const* X, const float* const*
     gw[d].M = V; gw[d].N = E; gw[d].K = (int)N; gw[d].nlive = nlive; gw[d].r0 = 0; gw[d].dev_bound = 2; gw[d].rows = rows;
     gw[d].extra = db[d]; gw[d].beta = 1; gw[d].prof_units = live;
   }
-  // Products of one kind share a launch while every one of them still gets at least two k-ranges per tile on its share
-  // of the grid (the small batches, where a launch is a chain of round trips); big ones run one after the other on the
-  // whole grid (157 row tiles of a 20 000-word vocabulary on half of the grid would be one k-range each).
-  float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
-  const long share = persistent_grid_blocks() / nd;
-  auto run = [&](bool akc, G224Args* g, long tiles) -> int {
-    if (nd > 1 && share / tiles >= 2) return launch_gemm_wide_n(akc, g, nd, s);
-    for (int d = 0; d < nd; ++d) { g[d].part = part; CVAE_TRY(launch_gemm_wide(akc, g[d], s)); }
+  auto to_gradient = [&](int d) -> int {
+    const int nblk = (int)(N < 8192 ? N : 8192);
+    hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, ga[d]);
+    CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
     return 0;
   };
-  CVAE_TRY(run(true, gx, cdiv(N, 128)));
-  CVAE_TRY(run(false, gw, cdiv(V, 128)));
+  // Small batches: the decoders' products of one kind share a launch (a launch there is a chain of round trips).  Taken
+  // while every product still gets two k-ranges per tile on its share of the grid (157 row tiles of a 20 000-word
+  // vocabulary on half of the grid would be one k-range each) and an item's chain of chunks stays short (V = 20 000 as
+  // the contraction length, dX at the Yelp shape: 357 us batched against 2 x 110 us one after the other).
+  const long share = persistent_grid_blocks() / nd;
+  auto small = [&](const G224Args& g, long tiles) {
+    const long ksb = share / tiles, kunits = cdiv(g.K, 16);
+    return nd > 1 && ksb >= 2 && kunits / ksb <= 64;
+  };
+  if (small(gx[0], cdiv(N, 128)) && small(gw[0], cdiv(V, 128))) {
+    for (int d = 0; d < nd; ++d) CVAE_TRY(to_gradient(d));
+    CVAE_TRY(launch_gemm_wide_n(true, gx, nd, s));
+    CVAE_TRY(launch_gemm_wide_n(false, gw, nd, s));
+    return 0;
+  }
+  // Big batches: decoder by decoder, so that a decoder's gradient w.r.t. its logits (232 MB at the Yelp shape) is
+  // still in the Infinity Cache when its two products read it.
+  float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
+  for (int d = 0; d < nd; ++d) {
+    CVAE_TRY(to_gradient(d));
+    gx[d].part = part; gw[d].part = part;
+    CVAE_TRY(launch_gemm_wide(true, gx[d], s));
+    CVAE_TRY(launch_gemm_wide(false, gw[d], s));
+  }
   return 0;
 }
 
