@@ -9,12 +9,16 @@ dev = torch.device('cuda:0'); _lib.init(0)
 cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 shape = data.SHAPES[os.environ.get('SHAPE', 'yelp')]
-hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'], batch_size=int(os.environ.get('BATCH', '32')))
+hp = harness.HParams(model=os.environ.get('MODEL', 'vae-couple'), cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'], batch_size=int(os.environ.get('BATCH', '32')))
 tr = harness.Trainer(hp, dev, seed=0)
 B = int(os.environ.get('BATCH', '32'))
 corpus = data.Corpus(data.synthetic_sentences(B * 8, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1000))
 sort_rows = os.environ.get('SORT_ROWS', '0') == '1'
-batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=sort_rows) for i in range(8)]
+if hp.is_dialog():       # MODEL=cvae-couple: posts and responses from two synthetic corpora
+    resps = data.Corpus(data.synthetic_sentences(B * 8, shape['V'], shape['mu'], shape['sigma'], shape['cap'], seed=1001))
+    batches = [harness.dialog_batch(corpus, resps, range(i * B, (i + 1) * B), dev) for i in range(8)]
+else:
+    batches = [harness.text_batch(corpus, range(i * B, (i + 1) * B), dev, sort_rows=sort_rows) for i in range(8)]
 for i in range(5):
     tr.train_step(batches[i % 8])
 torch.cuda.synchronize(); t0 = time.perf_counter()
