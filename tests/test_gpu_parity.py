@@ -3,6 +3,7 @@
 
 Bars (BASELINE.json north_star): indices bit-exact; loss / NLL / KL / MI / PPL within 1e-4
 relative; gradients within 1e-3 relative (per tensor, relative to its largest entry)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -462,6 +463,9 @@ def _train_step_vs_oracle(dev, model, cell, s, sents1, sents2, euclid=False, sor
         if P[k].grad is None:
             assert float(sd[k].grad.abs().max()) == 0.0, k
         else:
+            if os.environ.get('CVAE_TEST_PRINT_GRADS'):
+                print('grad rel %-50s %.3e  (max |ref| %.3e)' % (k, rel(sd[k].grad, P[k].grad), float(P[k].grad.abs().max())))
+                continue
             assert rel(sd[k].grad, P[k].grad) < GRAD_TOL, k
 
 
