@@ -14,7 +14,9 @@
  *  - workspaces are passed in by the caller.  Exceptions owned by the library, one set per (device, stream),
  *    allocated at their first use and regrown only when a larger shape arrives (warm-up; steady-state calls
  *    allocate nothing): the whole-sequence recurrent kernels' flag words and partial-gradient exchange, the
- *    split-K products' partial-sum slabs, and the live-row index lists of the backward passes.
+ *    split-K products' partial-sum slabs, the live-row index lists of the backward passes, the weight images of the
+ *    weight-streaming recurrent step kernels, the clip norm's per-block partial sums and (cvae_deterministic only)
+ *    the fixed-point buffer of the embedding-gradient scatter.
  *  - cell: 0 = GRU (gate rows r,z,n), 1 = LSTM (i,f,g,o), PyTorch equations and layouts.
  *    G = 3 or 4 below.
  */
