@@ -34,7 +34,36 @@ def main(argv):
     os.chdir(tree)
     sys.path[:0] = [dropin, os.path.join(ROOT, 'coupled-vae_amd'), tree]
     sys.argv = [script] + argv[3:]
+    pin_per_tensor_optimizer()
     runpy.run_path(script, run_name='__main__')
+
+
+def pin_per_tensor_optimizer():
+    """Experiment.train lists the shared embedding once per alias (CV/Experiment.py:589-600) and Experiment.step
+    hands that list to clip_grad_norm_ and Adam (:509-522).  Written against per-tensor loops, that means: the alias
+    gradient is scaled and stepped once per listing, one after the other (what the reference's CPU run records and
+    cvae_clip_adam reproduces).  torch >= 2 on a GPU defaults both calls to multi-tensor kernels, which apply the
+    in-place update to every listing of the same tensor CONCURRENTLY -- a data race with an undefined result.  The
+    launcher therefore makes foreach=False the default of the two names Experiment.py imports
+    (`from torch.optim import Adam`, `from torch.nn.utils import clip_grad_norm_`); an explicit foreach= still wins.
+    tests/test_gpu_reference_pattern.py drives the mirror through exactly these two calls against the fixtures."""
+    import functools
+    import torch
+
+    class Adam(torch.optim.Adam):
+        def __init__(self, params, *a, **k):
+            k.setdefault('foreach', False)
+            super().__init__(params, *a, **k)
+
+    torch.optim.Adam = Adam
+    _clip = torch.nn.utils.clip_grad_norm_
+
+    @functools.wraps(_clip)
+    def clip_grad_norm_(*a, **k):
+        k.setdefault('foreach', False)
+        return _clip(*a, **k)
+
+    torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
 
 
 if __name__ == '__main__':

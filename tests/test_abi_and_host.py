@@ -116,6 +116,21 @@ def test_run_reference_launcher_puts_the_dropin_first(tmp_path):
         from Modules.Losses.SeqLoss import SeqLoss
         from Modules.vae_couple import VAE_COUPLE
         print(SeqLoss.__module__, VAE_COUPLE.__module__, os.path.basename(os.getcwd()), sys.argv[1:], __name__)
+        # the two names Experiment.py imports run per-tensor unless told otherwise (the alias list must not race)
+        import torch
+        from torch.optim import Adam
+        from torch.nn.utils import clip_grad_norm_
+        w = torch.nn.Parameter(torch.ones(3))
+        w.grad = torch.full((3,), 100.0)
+        import warnings
+        warnings.simplefilter('ignore')
+        opt = Adam(params=[w, w], lr=0.5, betas=[0.9, 0.999], weight_decay=0)
+        assert opt.defaults['foreach'] is False and Adam(params=[w], foreach=True).defaults['foreach'] is True
+        clip_grad_norm_(parameters=[w, w], max_norm=1.0)     # norm counts the alias twice, scales it twice
+        c = 1.0 / ((2 * 3 * 100.0 ** 2) ** 0.5 + 1e-6)
+        assert abs(float(w.grad[0]) - 100.0 * c * c) < 1e-9, float(w.grad[0])
+        opt.step()                                           # two sequential Adam steps on the alias
+        assert int(opt.state[w]['step']) == 2
     '''))
     r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'run_reference.py'), str(tree), 'probe.py', 'x'],
                        capture_output=True, text=True, timeout=120)
