@@ -1162,7 +1162,14 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
                    float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
                    void* stream) {
   return launch_clip_adam(params, grads, m, v, n, alias_off, alias_n, alias_mult, max_norm, lr, beta1, beta2, eps,
-                          step_other, step_alias, sumsq, norm_out, S(stream));
+                          step_other, step_alias, 0, 0, 0, sumsq, norm_out, S(stream));
+}
+int cvae_clip_adam_late(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
+                        int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
+                        float eps, int64_t step_other, int64_t step_alias, int64_t late_off, int64_t late_n,
+                        int64_t step_late, float* sumsq, float* norm_out, void* stream) {
+  return launch_clip_adam(params, grads, m, v, n, alias_off, alias_n, alias_mult, max_norm, lr, beta1, beta2, eps,
+                          step_other, step_alias, late_off, late_n, step_late, sumsq, norm_out, S(stream));
 }
 int cvae_persist_status(void) { return persist_status_and_clear(); }
 int cvae_persist_status_peek(void) { return persist_status_peek(); }

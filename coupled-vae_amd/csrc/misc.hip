@@ -1087,54 +1087,79 @@ int launch_couple_bwd(const float* a, const float* c, const float* d, const floa
 // samples (kept in LDS), running sums for kl / xent.  Pass 2: max-shifted log-sum-exp.
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// kl_k = log q(z_k|x) - log p(z_k) is a difference of two sums of Z terms of size O(1) each (O(50) in all) that
+// leaves O(1): formed in fp32 it loses ~2e-6 absolute per sample, which is 5e-4 of a small KL.  Here every
+// per-dimension term and the sums over dimensions and samples are formed in double from the fp32 inputs (the
+// log sigma terms do not depend on the sample and are summed once per sentence), and rounded to fp32 once: the
+// result is the exactly-rounded value of the reference's expression, 1e-4 of the reference's own fp32 evaluation.
 __global__ __launch_bounds__(256) void iw_reduce_kernel(int K, int B, int Z, const float* __restrict__ z,
                                                         const float* __restrict__ xent, const float* __restrict__ mu,
                                                         const float* __restrict__ sigma,
                                                         const float* __restrict__ mu_p,
                                                         const float* __restrict__ sigma_p, float* __restrict__ nll,
                                                         float* __restrict__ kl, float* __restrict__ xent_mean) {
-  extern __shared__ float w[];          // [K] log-weights, then 3*4 floats of block-reduction space
-  float* red = w + K;
+  extern __shared__ float w[];          // [K] log-weights, then block-reduction space (doubles, 8-byte aligned)
+  double* red = reinterpret_cast<double*>(w + ((K + 1) & ~1));
+  __shared__ double s_logs;             // sum_j (log sigma_p[j] - log sigma[j]): the sample-independent part of kl_k
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float kl_acc = 0.f, x_acc = 0.f, wmax = -INFINITY;
+  if (wave == 0) {
+    double a = 0.0;
+    for (int j = lane; j < Z; j += 64) {
+      a -= log((double)sigma[(long)b * Z + j]);
+      if (mu_p) a += log((double)sigma_p[(long)b * Z + j]);
+    }
+    a = wave_sum_f64(a);
+    if (lane == 0) s_logs = a;
+  }
+  __syncthreads();
+  const double logs = s_logs;
+  double kl_acc = 0.0, x_acc = 0.0;
+  float wmax = -INFINITY;
   for (int k = tid; k < K; k += blockDim.x) {
     const float* zk = z + ((long)k * B + b) * Z;
-    float lq = 0.f, lp = 0.f;
+    double d = logs;                    // log q - log p of this sample
     for (int j = 0; j < Z; ++j) {
-      const float zv = zk[j], m = mu[(long)b * Z + j], sg = sigma[(long)b * Z + j];
-      lq += -((zv - m) * (zv - m)) / (2.f * sg * sg) - logf(sg) - kHalfLog2Pi;
+      const double zv = zk[j], m = mu[(long)b * Z + j], sg = sigma[(long)b * Z + j];
+      d -= ((zv - m) * (zv - m)) / (2.0 * sg * sg);
       if (mu_p) {
-        const float mp = mu_p[(long)b * Z + j], sp = sigma_p[(long)b * Z + j];
-        lp += -((zv - mp) * (zv - mp)) / (2.f * sp * sp) - logf(sp) - kHalfLog2Pi;
+        const double mp = mu_p[(long)b * Z + j], sp = sigma_p[(long)b * Z + j];
+        d += ((zv - mp) * (zv - mp)) / (2.0 * sp * sp);
       } else {
-        lp += -(zv * zv) * 0.5f - kHalfLog2Pi;
+        d += zv * zv * 0.5;
       }
     }
     const float xe = xent[(long)k * B + b];
-    const float wk = lp - xe - lq;
+    const float wk = (float)(-d - (double)xe);        // log p(z) + log p(x|z) - log q(z|x)
     w[k] = wk;
     wmax = fmaxf(wmax, wk);
-    kl_acc += lq - lp;
-    x_acc += xe;
+    kl_acc += d;
+    x_acc += (double)xe;
   }
-  kl_acc = wave_sum(kl_acc); x_acc = wave_sum(x_acc); wmax = wave_max(wmax);
-  if (lane == 0) { red[wave] = kl_acc; red[4 + wave] = x_acc; red[8 + wave] = wmax; }
+  kl_acc = wave_sum_f64(kl_acc); x_acc = wave_sum_f64(x_acc); wmax = wave_max(wmax);
+  if (lane == 0) { red[wave] = kl_acc; red[4 + wave] = x_acc; red[8 + wave] = (double)wmax; }
   __syncthreads();
   const int nw = blockDim.x >> 6;
-  float M = -INFINITY, klt = 0.f, xt = 0.f;
-  for (int i = 0; i < nw; ++i) { klt += red[i]; xt += red[4 + i]; M = fmaxf(M, red[8 + i]); }
+  float M = -INFINITY;
+  double klt = 0.0, xt = 0.0;
+  for (int i = 0; i < nw; ++i) { klt += red[i]; xt += red[4 + i]; M = fmaxf(M, (float)red[8 + i]); }
   __syncthreads();
   float sacc = 0.f;
   for (int k = tid; k < K; k += blockDim.x) sacc += expf(w[k] - M);
   sacc = wave_sum(sacc);
-  if (lane == 0) red[wave] = sacc;
+  if (lane == 0) red[wave] = (double)sacc;
   __syncthreads();
   if (tid == 0) {
     float st = 0.f;
-    for (int i = 0; i < nw; ++i) st += red[i];
+    for (int i = 0; i < nw; ++i) st += (float)red[i];
     nll[b] = -(M + logf(st) - logf((float)K));
-    kl[b] = klt / K;
-    xent_mean[b] = xt / K;
+    kl[b] = (float)(klt / K);
+    xent_mean[b] = (float)(xt / K);
   }
 }
 int launch_iw_reduce(const float* z, const float* xent, const float* mu, const float* sigma, const float* mu_p,
@@ -1144,7 +1169,7 @@ int launch_iw_reduce(const float* z, const float* xent, const float* mu, const f
   CVAE_REQUIRE(K <= 12000, "iw_reduce: K=%d exceeds the LDS-resident limit (12000)", K);
   CVAE_REQUIRE((mu_p == nullptr) == (sigma_p == nullptr), "iw_reduce: prior needs both mu_p and sigma_p");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(iw_reduce_kernel, dim3(B), dim3(256), (K + 12) * sizeof(float), s, K, B, Z, z, xent, mu, sigma,
+  hipLaunchKernelGGL(iw_reduce_kernel, dim3(B), dim3(256), (((K + 1) & ~1) + 24) * sizeof(float), s, K, B, Z, z, xent, mu, sigma,
                      mu_p, sigma_p, nll, kl, xent_mean);
   CVAE_LAUNCH_CHECK("iw_reduce_kernel");
   return 0;
@@ -1255,9 +1280,9 @@ int launch_mi_static(const float* z, const float* mu, const float* sigma, int K,
 // out[b] = block b's sum over all grads^2, out[SUMSQ_MAX_BLOCKS + b] = its sum over the alias segment.  No float
 // atomics: the clip norm is the same bits on every run (and on every rank of a data-parallel job).
 constexpr int SUMSQ_MAX_BLOCKS = 256;
-__global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, const float* __restrict__ g,
-                                                     float* __restrict__ out, const int* __restrict__ status_in,
-                                                     int* __restrict__ status_copy) {
+__global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, long skip0, long skip1,
+                                                     const float* __restrict__ g, float* __restrict__ out,
+                                                     const int* __restrict__ status_in, int* __restrict__ status_copy) {
   __shared__ float red[2][16];
   // one read of the recurrent kernels' timeout word (host-mapped) per optimizer step: clip_adam_kernel
   // reads the device copy and leaves the parameters alone when a kernel of this step timed out
@@ -1265,7 +1290,7 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, c
     *status_copy = status_in ? __hip_atomic_load(status_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
   float all = 0.f, al = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float v = g[i];
+    const float v = (i >= skip0 && i < skip1) ? 0.f : g[i];      // a group without a gradient this iteration
     all += v * v;
     if (i >= a0 && i < a1) al += v * v;
   }
@@ -1284,9 +1309,13 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long n, long a0, long a1, c
 
 struct AdamSteps { float step_size[8]; float bc2_sqrt[8]; };   // per listing: lr/(1-b1^t), sqrt(1-b2^t)
 
+// [l0, l1): the "late" parameter group (launch_clip_adam): its own step count (late.step_size[0]), or, with
+// late_skip, no gradient this iteration: left exactly as it is, as torch's clip and Adam leave a parameter whose
+// .grad is None.
 __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1, int mult, float max_norm,
                                                         float b1, float b2, float eps, AdamSteps other,
-                                                        AdamSteps alias_steps, const float* __restrict__ parts,
+                                                        AdamSteps alias_steps, long l0, long l1, int late_skip,
+                                                        AdamSteps late, const float* __restrict__ parts,
                                                         int nparts, float* __restrict__ sumsq,
                                                         float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
@@ -1315,6 +1344,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1
   coef = coef > 1.f ? 1.f : coef;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const bool alias = (i >= a0 && i < a1);
+    const bool is_late = (i >= l0 && i < l1);
+    if (is_late && late_skip) continue;
     const int reps = alias ? mult : 1;
     float gv = g[i];
     for (int r = 0; r < reps; ++r) gv *= coef;        // scaled once per listing
@@ -1323,8 +1354,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1
     for (int r = 0; r < reps; ++r) {                  // one full Adam step per listing
       mv = mv + (gv - mv) * (1.f - b1);               // lerp_
       vv = vv * b2 + gv * gv * (1.f - b2);
-      const float ss = alias ? alias_steps.step_size[r] : other.step_size[0];
-      const float bs = alias ? alias_steps.bc2_sqrt[r] : other.bc2_sqrt[0];
+      const float ss = alias ? alias_steps.step_size[r] : (is_late ? late.step_size[0] : other.step_size[0]);
+      const float bs = alias ? alias_steps.bc2_sqrt[r] : (is_late ? late.bc2_sqrt[0] : other.bc2_sqrt[0]);
       const float denom = sqrtf(vv) / bs + eps;
       pv = pv - ss * (mv / denom);
     }
@@ -1335,7 +1366,15 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(long n, long a0, long a1
 
 int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
                      float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
-                     float* sumsq, float* norm_out, hipStream_t s) {
+                     long late_off, long late_n, long step_late, float* sumsq, float* norm_out, hipStream_t s) {
+  // arguments first: nothing is acquired or launched for a call that is refused
+  CVAE_REQUIRE(n >= 0 && alias_off >= 0 && alias_n >= 0 && alias_off + alias_n <= n && mult >= 1 && mult <= 8,
+               "clip_adam: bad segment (alias_mult must be 1..8)");
+  CVAE_REQUIRE(late_off >= 0 && late_n >= 0 && late_off + late_n <= n &&
+               (late_n == 0 || alias_n == 0 || late_off >= alias_off + alias_n || late_off + late_n <= alias_off),
+               "clip_adam: the late segment must lie inside the arena and outside the alias segment");
+  if (n == 0) return 0;
+  CVAE_REQUIRE(p && g && m && v && sumsq, "clip_adam: null operand");
   // timeout word of the whole-sequence recurrent kernels and a device-side copy of it (a spare word of this
   // stream's sync buffer)
   int* status_in = nullptr;
@@ -1343,10 +1382,6 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
   void* syncbuf = nullptr;
   CVAE_TRY(lib_scratch(LS_PERSIST_SYNC, s, persist_sync_bytes(), &syncbuf, 1));
   int* status_copy = persist_status_copy_word(syncbuf);
-  CVAE_REQUIRE(n >= 0 && alias_off >= 0 && alias_n >= 0 && alias_off + alias_n <= n && mult >= 1 && mult <= 8,
-               "clip_adam: bad segment (alias_mult must be 1..8)");
-  if (n == 0) return 0;
-  CVAE_REQUIRE(p && g && m && v && sumsq, "clip_adam: null operand");
   void* partbuf = nullptr;
   CVAE_TRY(lib_scratch(LS_SUMSQ, s, 2 * SUMSQ_MAX_BLOCKS * sizeof(float), &partbuf));
   float* parts = static_cast<float*>(partbuf);
@@ -1356,10 +1391,15 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
   int sgrid = cdiv(n, 1024 * 8);
   if (sgrid > SUMSQ_MAX_BLOCKS) sgrid = SUMSQ_MAX_BLOCKS;
   if (sgrid < 1) sgrid = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n, g, parts,
-                     status_in, status_copy);
+  const bool late_skip = late_n > 0 && step_late < 0;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(sgrid), dim3(1024), 0, s, n, alias_off, alias_off + alias_n,
+                     late_skip ? late_off : 0L, late_skip ? late_off + late_n : 0L, g, parts, status_in, status_copy);
   CVAE_LAUNCH_CHECK("sumsq_kernel");
-  AdamSteps so = {}, sa = {};
+  AdamSteps so = {}, sa = {}, sl = {};
+  if (late_n > 0 && step_late >= 0) {
+    sl.step_size[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_late + 1))));
+    sl.bc2_sqrt[0] = (float)sqrt(1.0 - pow((double)b2, (double)(step_late + 1)));
+  }
   so.step_size[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_other + 1))));
   so.bc2_sqrt[0] = (float)sqrt(1.0 - pow((double)b2, (double)(step_other + 1)));
   for (int r = 0; r < mult; ++r) {
@@ -1367,7 +1407,8 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
     sa.bc2_sqrt[r] = (float)sqrt(1.0 - pow((double)b2, (double)(step_alias + 1 + r)));
   }
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, mult,
-                     max_norm, b1, b2, eps, so, sa, parts, sgrid, sumsq, p, g, m, v, norm_out, status_copy);
+                     max_norm, b1, b2, eps, so, sa, late_off, late_off + late_n, late_skip ? 1 : 0,
+                     sl, parts, sgrid, sumsq, p, g, m, v, norm_out, status_copy);
   CVAE_LAUNCH_CHECK("clip_adam_kernel");
   return 0;
 }

@@ -82,7 +82,7 @@ int launch_mi_static(const float* z, const float* mu, const float* sigma, int K,
                      hipStream_t s);
 int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
                      float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
-                     float* sumsq, float* norm_out, hipStream_t s);
+                     long late_off, long late_n, long step_late, float* sumsq, float* norm_out, hipStream_t s);
 
 // projce.hip
 long projce_workspace_floats(int N, int V);

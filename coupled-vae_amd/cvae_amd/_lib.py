@@ -82,6 +82,7 @@ SIGNATURES = {
     'cvae_mi_static': [P, P, P, I, I, I, P, P],
     'cvae_mi_static_max_rows': [],
     'cvae_clip_adam': [P, P, P, P, L, L, L, I, F, F, F, F, F, L, L, P, P, P],
+    'cvae_clip_adam_late': [P, P, P, P, L, L, L, I, F, F, F, F, F, L, L, L, L, L, P, P, P],
     'cvae_deterministic': [I],
     'cvae_profile_enable': [I],
     'cvae_profile_read': [I, P, P, P],

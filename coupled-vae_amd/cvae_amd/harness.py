@@ -117,6 +117,10 @@ class FlatAdam(object):
         for p in uniq:
             self.offsets.append(off)
             off += pad4(p.numel())
+        # steps each parameter has taken: torch's Adam keeps one count per parameter and skips a parameter whose
+        # gradient is None (the BoW head while lambda_KL <= 1e-5, CV/Experiment.py:711-713): see step()
+        self.taken = [0] * len(uniq)
+        self._none_now = [False] * len(uniq)
         self.buckets = None            # data-parallel gradient buckets (arm_buckets)
         self.hooks_live = False        # hooks act only inside Trainer.forward_backward's backward pass
         self.issued_early = 0          # buckets of the last step whose collective started inside the backward pass
@@ -159,9 +163,20 @@ class FlatAdam(object):
             if not self.hooks_live or self.buckets is None or bucket['fired']:
                 return
             bucket['arrived'] += 1
-            if bucket['arrived'] == len(bucket['members']):
-                self._fire(bucket)
+            self._fire_ready()
         return hook
+
+    def _fire_ready(self):
+        """Collectives go out in ONE order on every rank, whatever order the hooks arrive in: highest arena offset
+        first (the backward pass produces ToVocab's and the decoders' gradients first, and they sit last in the
+        arena), a bucket only after every later bucket.  A bucket that is complete but blocked waits for its turn
+        (finish_allreduce issues whatever is left in the same order)."""
+        for b in reversed(self.buckets):
+            if b['fired']:
+                continue
+            if b['arrived'] < len(b['members']):
+                return
+            self._fire(b)
 
     def _fire(self, bucket):
         src, dst = [], []
@@ -184,18 +199,38 @@ class FlatAdam(object):
         self.hooks_live = False
         if self.buckets is None:
             self._had_grad = [p.grad is not None for p in self.views]
+        # a parameter outside the set learnt on the first step that has a gradient now (a loss term that switched
+        # on: the BoW head once lambda_KL > 1e-5): if the bucket that covers its arena range is already in flight,
+        # gather_grads' copy comes too late for that collective and the range gets one of its own below
+        extra = []
+        if self.buckets is not None:
+            for i, p in enumerate(self.views):
+                if p.grad is not None and not self._had_grad[i]:
+                    b = next(b for b in self.buckets if b['lo'] <= self.offsets[i] < b['hi'])
+                    if b['fired']:
+                        extra.append(i)
         self.gather_grads()
         if self.buckets is None:
             dist_utils.allreduce_mean_(self.grads)
             return
-        for b in self.buckets:
-            if not b['fired']:
-                b['work'] = dist_utils.allreduce_sum_async(self.grads[b['lo']:b['hi']])
-        for b in self.buckets:
-            if b['work'] is not None:
-                b['work'].wait()
-            b['work'], b['fired'], b['arrived'] = None, False, 0
+        try:
+            for b in reversed(self.buckets):                 # the same order as _fire_ready
+                if not b['fired']:
+                    b['work'] = dist_utils.allreduce_sum_async(self.grads[b['lo']:b['hi']])
+            for b in self.buckets:
+                if b['work'] is not None:
+                    b['work'].wait()
+            for i in extra:                                  # same parameters, same order on every rank
+                dist_utils.allreduce_sum_async(self.gviews[i].view(-1)).wait()
+        finally:
+            self.reset_buckets()
         self.grads.mul_(1.0 / world)
+
+    def reset_buckets(self):
+        """Bucket state of the iteration is dropped (also after a backward pass that raised)."""
+        self.hooks_live = False
+        for b in self.buckets or []:
+            b['work'], b['fired'], b['arrived'] = None, False, 0
 
     def zero_grad(self):
         """Gradients are produced outside the arena and gathered once after backward (gather_grads):
@@ -209,8 +244,12 @@ class FlatAdam(object):
         afterwards.  Segments of parameters without a gradient (None in the reference too) keep the
         zeros they were created with: nothing ever writes them."""
         src, dst = [], []
-        for p, g in zip(self.views, self.gviews):
-            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+        for i, (p, g) in enumerate(zip(self.views, self.gviews)):
+            self._none_now[i] = p.grad is None
+            if p.grad is None:
+                if self.taken[i] > 0:          # had a gradient in an earlier iteration: the arena still holds it
+                    g.zero_()
+            elif p.grad.data_ptr() != g.data_ptr():
                 src.append(p.grad)
                 dst.append(g)
         if src:
@@ -218,10 +257,35 @@ class FlatAdam(object):
         for p, g in zip(self.views, self.gviews):
             p.grad = g
 
+    def _late_group(self):
+        """torch's Adam counts steps per parameter and, like clip_grad_norm_, passes over a parameter whose .grad
+        is None (CV/Experiment.py:509-522).  Parameters that never had a gradient need nothing: their arena
+        gradient, m and v are zero and the update is exactly zero.  Parameters that receive their FIRST gradient
+        after the model's first step (the BoW head behind `lambda_KL > 1e-5`, :711-713), or lose it again, form
+        the "late" group of cvae_clip_adam_late: one contiguous arena range with one step count.
+        -> None or (offset, n, steps taken; -1 = no gradient now)."""
+        late = [i for i, none in enumerate(self._none_now)
+                if (not none and self.taken[i] != self.steps) or (none and self.taken[i] > 0)]
+        if not late:
+            return None
+        lo, hi = late[0], late[-1]
+        state = {(self._none_now[i], self.taken[i]) for i in late}
+        if late != list(range(lo, hi + 1)) or len(state) != 1 or self.views[lo] is self.views[0] and self.alias_n:
+            raise NotImplementedError('parameters with %d different (gradient present, steps taken) histories: '
+                                      'cvae_clip_adam_late takes one contiguous late group' % len(state))
+        none, taken = next(iter(state))
+        end = self.offsets[hi] + self.views[hi].numel()
+        return self.offsets[lo], end - self.offsets[lo], (-1 if none else taken)
+
     def step(self):
         mult = max(self.n_alias, 1)
+        late = self._late_group()
         ops.clip_adam(self.params, self.grads, self.m, self.v, 0, self.alias_n, mult, self.hp.clip_norm, self.lr,
-                      (self.hp.beta1, self.hp.beta2), 1e-8, self.steps, self.steps * mult, self.sumsq, self.norm)
+                      (self.hp.beta1, self.hp.beta2), 1e-8, self.steps, self.steps * mult, self.sumsq, self.norm,
+                      late=late)
+        for i, none in enumerate(self._none_now):
+            if not none:
+                self.taken[i] += 1
         self.steps += 1
 
 
@@ -281,16 +345,26 @@ class Trainer(object):
             coef += [hp.lambda_seq_couple, hp.lambda_couple]
             terms += [m.criterionSeq(logits_c, eos, keep_batch=True),
                       ops.couple_loss(init, init_c, hp.Z, hp.euclidean_dist)]
+        bow_off = None
         if hp.lambda_BoW > 0 and not hp.is_dialog():
-            # bag-of-words loss (CV/Experiment.py:703-706, 713-715, 737-740): cross-entropy of BoW(z) against every
-            # token of the sentence, per sentence divided by its length; enters the total only once lambda_KL > 1e-5
+            # bag-of-words loss (CV/Experiment.py:703-706, 737-740): cross-entropy of BoW(z) against every token of
+            # the sentence, per sentence divided by its length.  It enters the total only once lambda_KL > 1e-5
+            # (:711-713, 759-761); until then it is computed for the log alone and the BoW head has NO gradient
+            # (None in the reference: its clip and Adam pass over the head, FlatAdam._late_group)
             L = batch['bare'].shape[1]
-            bow = m.criterionSeq(bow_logits.unsqueeze(1).expand(-1, L, -1), batch['bare'], keep_batch=True)
-            names.append('bow')
-            coef.append(hp.lambda_BoW if lam > 1e-5 else 0.0)
-            terms.append(bow / batch['len'].to(bow.dtype))
+            with torch.set_grad_enabled(lam > 1e-5):
+                bow = m.criterionSeq(bow_logits.unsqueeze(1).expand(-1, L, -1), batch['bare'], keep_batch=True)
+                bow = bow / batch['len'].to(bow.dtype)
+            if lam > 1e-5:
+                names.append('bow')
+                coef.append(hp.lambda_BoW)
+                terms.append(bow)
+            else:
+                bow_off = bow.mean(0)
         tot, means = ops.loss_assemble(terms, coef)
         res = {nm: means[i] for i, nm in enumerate(names)}
+        if bow_off is not None:
+            res['bow'] = bow_off
         res['tot'] = tot.view(())
         res['lambda_kl'] = lam
         return res
@@ -308,7 +382,11 @@ class Trainer(object):
             settings.restore_row_order = keep
         self.opt.hooks_live = self.world > 1
         self.opt.issued_early = 0
-        res['tot'].backward()
+        try:
+            res['tot'].backward()
+        except BaseException:
+            self.opt.reset_buckets()           # no stale 'fired' / in-flight state after a failed backward pass
+            raise
         if self.world > 1:
             # the batch mean over equal per-rank batches = mean of per-rank gradients; must
             # complete before the clip (Experiment.py:515 clips the full-batch gradient).  Buckets whose

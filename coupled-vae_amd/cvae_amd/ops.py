@@ -827,6 +827,13 @@ def mi_static(z, mu, sigma, out=None):
 
 # --------------------------------------------------------------------------- optimizer
 def clip_adam(params, grads, m, v, alias_off, alias_n, alias_mult, max_norm, lr, betas, eps, step_other, step_alias,
-              sumsq, norm_out):
-    call('cvae_clip_adam', ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), alias_off, alias_n, alias_mult,
-         max_norm, lr, betas[0], betas[1], eps, step_other, step_alias, ptr(sumsq), ptr(norm_out), stream())
+              sumsq, norm_out, late=None):
+    """late: None or (offset, n, steps_taken) of the parameter group with its own step count; steps_taken < 0 = the
+    group has no gradient this iteration (cvae_clip_adam_late)."""
+    if late is None:
+        call('cvae_clip_adam', ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), alias_off, alias_n, alias_mult,
+             max_norm, lr, betas[0], betas[1], eps, step_other, step_alias, ptr(sumsq), ptr(norm_out), stream())
+    else:
+        call('cvae_clip_adam_late', ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), alias_off, alias_n,
+             alias_mult, max_norm, lr, betas[0], betas[1], eps, step_other, step_alias, int(late[0]), int(late[1]),
+             int(late[2]), ptr(sumsq), ptr(norm_out), stream())

@@ -319,6 +319,17 @@ int cvae_clip_adam(float* params, float* grads, float* m, float* v, int64_t n, i
                    int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
                    float eps, int64_t step_other, int64_t step_alias, float* sumsq, float* norm_out,
                    void* stream);
+/* The same with one more parameter group, [late_off, late_off + late_n) (outside the alias segment): parameters
+ * whose gradient is None in some iterations of the reference.  torch's clip_grad_norm_ and Adam skip a parameter
+ * without a gradient: it does not count in the norm, m / v / the parameter stay as they are and its per-parameter
+ * step count does not advance -- the BoW head while `lambda_KL <= 1e-5` leaves the bag-of-words term out of the
+ * total (CV/Experiment.py:711-713, 759-761; step at :509-522).  step_late = the number of steps THIS group has
+ * taken before the call (its bias corrections use step_late + 1); step_late < 0 = the group has no gradient in this
+ * iteration and is skipped as above.  late_n = 0: cvae_clip_adam. */
+int cvae_clip_adam_late(float* params, float* grads, float* m, float* v, int64_t n, int64_t alias_off,
+                        int64_t alias_n, int alias_mult, float max_norm, float lr, float beta1, float beta2,
+                        float eps, int64_t step_other, int64_t step_alias, int64_t late_off, int64_t late_n,
+                        int64_t step_late, float* sumsq, float* norm_out, void* stream);
 
 /* ---- arithmetic of the large dense products (no reference counterpart: torch computes them in fp32).  The
  * hidden x vocab product of cvae_projce_* (E <= 200, E % 8 == 0, 16-byte rows) and the many-row recurrent gate

@@ -66,6 +66,15 @@ JOBS = [
      dict(TINY, annealing_start=-10000000, annealing_step=10, lambda_fb=0.3)),
     ('text_dae_gru_tiny', 'Coupled-VAE', 'ptb', 'dae', 'gru', TINY),
     ('text_lm_gru_tiny', 'Coupled-VAE', 'ptb', 'lm', 'gru', TINY),
+    # bag-of-words loss (CV/Experiment.py:703-715, 737-740, 759-761; lambda_BoW is 0 in every shipped config and is
+    # substituted here).  Four recorded iterations (two epochs of two batches) across the reference's `lambda_KL > 1e-5` gate: with
+    # annealing_start = annealing_step = 1 lambda_KL is 0 at iteration 1 (the BoW term is left out of the total: the
+    # BoW head's gradient is None and torch's clip / Adam skip it) and 1 from iteration 2 on (the term enters, and
+    # the BoW head takes ITS first Adam step at the model's second).
+    ('text_vae-couple-bow_gru_tiny', 'Coupled-VAE', 'ptb', 'vae-couple', 'gru',
+     dict(TINY, annealing_start=1, annealing_step=1, lambda_BoW=0.5, num_iters=4)),
+    ('text_vae-bow_lstm_tiny', 'Coupled-VAE', 'ptb', 'vae', 'lstm',
+     dict(TINY, annealing_start=1, annealing_step=1, lambda_BoW=0.5, num_iters=4)),
 ]
 BASE_MODEL = {'beta-vae': 'vae', 'cyc-anneal-vae': 'vae', 'cyc-anneal-vae-couple': 'vae-couple', 'surprising-fix': 'vae'}
 
@@ -132,7 +141,9 @@ def _patched_config_source(tree, dataset, model, cell, shp):
     src = src.replace('self.batch_size = 32', 'self.batch_size = %d' % shp['B'])
     src = src.replace('self.num_workers = 8', 'self.num_workers = 0')
     src = src.replace('self.use_tensorboard = True', 'self.use_tensorboard = False')
-    src = src.replace('self.num_iters = 60000', 'self.num_iters = 2')
+    src = src.replace('self.num_iters = 60000', 'self.num_iters = %d' % shp.get('num_iters', 2))
+    if 'lambda_BoW' in shp:
+        src = src.replace('self.lambda_BoW = 0', 'self.lambda_BoW = %r' % shp['lambda_BoW'])
     if 'annealing_start' in shp:
         src = re.sub(r'self\.annealing_start = \d+', 'self.annealing_start = %d' % shp['annealing_start'], src)
         src = re.sub(r'self\.annealing_step = \d+', 'self.annealing_step = %d' % shp['annealing_step'], src)
@@ -169,6 +180,89 @@ def _write_corpus(tree, dataset, shp):
                     f.write(' '.join(sent()) + '\t' + ' '.join(sent()) + '\n')
                 else:
                     f.write(' '.join(sent()) + '\n')
+
+
+def _analysis_fixtures(exp, ae, E, rec, out, meta, shp, base, tb):
+    """gen_interps / sample_from_posterior / saliency of the text models (CV/Modules/vae_couple.py:583-633, 657-679,
+    743-778; vae.py:230-278, 348-374) on the first sentences of the test set, with the weights under 'eval/'.
+    Recorded: inputs, every noise draw, and what the reference's callers compute from the results
+    (Experiment.interpolation: decoded ids; Experiment.analyze_saliency, CV/Experiment.py:1543-1619: the gradient of
+    each loss term with respect to the encoder state, and dhde)."""
+    import torch
+    from Modules.Losses.SeqLoss import SeqLoss
+    bare, go, eos, ln = tb
+    B, Z = shp['B'], shp['Z']
+    go1 = torch.zeros(B, 1, dtype=torch.long) + exp.test_set.go
+    # ---- gen_interps: evaluation mode (greedy decode of n + 2 points between the two posterior means)
+    ae.train(False)
+    A, Bs = slice(0, B), slice(B, 2 * B)
+    n_interps = 3
+    with torch.no_grad():
+        interps = ae.gen_interps(bareA=bare[A], sent_lenA=ln[A], bareB=bare[Bs], sent_lenB=ln[Bs], go=go1,
+                                 n_interps=n_interps)
+    out['interp/bareA'], out['interp/lenA'] = bare[A].numpy(), ln[A].numpy()
+    out['interp/bareB'], out['interp/lenB'] = bare[Bs].numpy(), ln[Bs].numpy()
+    out['interp/go'] = go1.numpy()
+    out['interp/ids'] = np.asarray([[[int(t.item()) for t in sent] for sent in per_b] for per_b in interps],
+                                   dtype=np.int64)                       # (B, n_interps + 2, max_len)
+    meta['n_interps'] = n_interps
+    # ---- sample_from_posterior: Normal.sample draws through torch.normal(mean, std), which computes
+    # mean + std * N(0,1): the shim below does exactly that with a recorded standard-normal draw
+    n_sample = 5
+    _orig_normal = torch.normal
+    drawn = []
+
+    def rec_normal(mean, std, *a, **k):
+        e = torch.randn(mean.shape)
+        drawn.append(e.clone())
+        return mean + std * e
+
+    torch.normal = rec_normal
+    try:
+        with torch.no_grad():
+            smp = ae.sample_from_posterior(bare=bare[A], sent_len=ln[A], n_sample=n_sample)
+    finally:
+        torch.normal = _orig_normal
+    assert len(drawn) == 1 and tuple(drawn[0].shape) == (n_sample, B, Z)
+    out['postsample/eps'], out['postsample/samples'] = drawn[0].numpy(), smp.numpy()   # samples (B, n_sample, Z)
+    # ---- saliency: training mode (analyze_saliency calls set_training(True): dropout is live)
+    ae.train(True)
+    crit = SeqLoss(voc_size=exp.test_set.vocab.size, pad=exp.test_set.pad, end=exp.test_set.eos, unk=exp.test_set.unk)
+    rec['noise'].clear()
+    res = ae.saliency(bare=bare[A], sent_len=ln[A], go=go[A])
+    names = NOISE_ORDER[base]
+    assert len(rec['noise']) == len(names)
+    for nm, (kind, t) in zip(names, rec['noise']):
+        assert (kind == 'eps') == nm.startswith('eps'), (nm, kind)
+        out['saliency/noise/' + nm] = t.squeeze(0).numpy() if kind == 'eps' else t.numpy()
+    if base == 'vae':
+        logits, dist, init, last = res
+        logits_c = None
+    else:
+        logits, logits_c, dist, init, init_c, last = res
+    grad = lambda y: torch.autograd.grad(outputs=y, inputs=last, create_graph=False, retain_graph=True,
+                                         only_inputs=True)[0]
+    seq = crit(logits, eos[A], keep_batch=True).sum(0)
+    std = torch.distributions.Normal(torch.zeros(Z), torch.ones(Z))
+    kl = torch.distributions.kl_divergence(dist, std).sum(1).sum(0)
+    out['saliency/bare'], out['saliency/go'] = bare[A].numpy(), go[A].numpy()
+    out['saliency/eos'], out['saliency/len'] = eos[A].numpy(), ln[A].numpy()
+    out['saliency/last'], out['saliency/init'] = last.detach().numpy(), init.detach().numpy()
+    out['saliency/seq_sum'] = np.float64(seq.item())
+    out['saliency/d_seq'] = grad(seq).numpy()
+    out['saliency/d_kl'] = grad(kl).numpy()
+    if logits_c is not None:
+        seq_c = crit(logits_c, eos[A], keep_batch=True).sum(0)
+        out['saliency/init_couple'] = init_c.detach().numpy()
+        out['saliency/seq_c_sum'] = np.float64(seq_c.item())
+        out['saliency/d_seq_c'] = grad(seq_c).numpy()
+        out['saliency/d_seq_tot'] = grad(seq + seq_c).numpy()
+    dhde = 0
+    for _init in init.sum(0):
+        dhde = dhde + (grad(_init) ** 2).sum(1)
+    out['saliency/dhde'] = (dhde / torch.sum(init ** 2, dim=1)).detach().numpy()
+    rec['noise'].clear()
+    ae.train(False)
 
 
 def child(name, tree, dataset, model, cell, shp, out_path):
@@ -333,17 +427,21 @@ def child(name, tree, dataset, model, cell, shp, out_path):
     h.remove()
     exp.step = _orig_step
     exp.preprocess_data = _orig_pre
-    assert len(steps) == 2, len(steps)
-    meta['n_train_steps'] = 2
+    n_it = shp.get('num_iters', 2)
+    assert len(steps) == n_it, len(steps)
+    meta['n_train_steps'] = n_it
+    meta['lambda_BoW'] = float(shp.get('lambda_BoW', 0.0))
     meta['trainable_entries'] = steps[0][2]
     meta['trainable_unique'] = steps[0][3]
     base = BASE_MODEL.get(model, model)
     names = NOISE_ORDER[base]
     per = len(names)
-    assert len(rec['noise']) == 2 * per, (len(rec['noise']), per)
+    assert len(rec['noise']) == n_it * per, (len(rec['noise']), per)
     coupled = model.endswith('couple')
     lean = bool(shp.get('lean'))
-    for it in range(2):
+    with_bow = shp.get('lambda_BoW', 0.0) > 0
+    meta['none_grad_keys_per_step'] = []
+    for it in range(n_it):
         p = 'train/%d/' % it
         data = batches[it]
         if tree == 'Coupled-VAE':
@@ -386,8 +484,11 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             out[p + 'logits'] = logits.detach().numpy()
         if dist is not None:
             out[p + 'mu'], out[p + 'sigma'] = dist.loc.detach().numpy(), dist.scale.detach().numpy()
-        nseq = 2 if coupled else 1
+        nseq = (2 if coupled else 1) + (1 if with_bow else 0)   # criterionSeq calls per iteration: seq [, seq_c] [, bow]
         out[p + 'seq_per_sent'] = rec['seq'][it * nseq].numpy()
+        if with_bow:
+            # criterionSeq(BoW_logits expanded, bare, keep_batch=True): per-sentence sums BEFORE the division by sent_len
+            out[p + 'bow_sum_per_sent'] = rec['seq'][it * nseq + nseq - 1].numpy()
         if coupled:
             out[p + 'seq_c_per_sent'] = rec['seq'][it * nseq + 1].numpy()
             out[p + 'euc'] = rec['euc'][it].numpy()
@@ -399,9 +500,10 @@ def child(name, tree, dataset, model, cell, shp, out_path):
         for k in keys_all:
             if g[k] is not None:
                 out[p + 'grad/' + k] = g[k].numpy()
-            if not lean or it == 1:
+            if not lean or it == n_it - 1:
                 out[p + 'post/' + k] = w[k].numpy()
         meta.setdefault('none_grad_keys', [k for k in keys_all if g[k] is None])
+        meta['none_grad_keys_per_step'].append([k for k in keys_all if g[k] is None])
     rec['noise'].clear(); rec['seq'].clear(); rec['kl'].clear(); rec['euc'].clear()
 
     def finish():
@@ -556,6 +658,8 @@ def child(name, tree, dataset, model, cell, shp, out_path):
             ae.Decoder.beam_size = 1
             out['beam/ids'] = np.asarray([[int(t.item()) for t in srow] for srow in sents_b], dtype=np.int64)
             meta['beam_size'] = 3
+        if not lean:
+            _analysis_fixtures(exp, ae, E, rec, out, meta, shp, base, tb)
     else:
         sd_np('eval/')
         # ---- generation (8f.3): sample_from_prior on one val batch -- post encoder, z from the prior

@@ -54,7 +54,14 @@ class Golden(object):
         m = self.meta
         return dict(latent_dim=m['Z'], lambda_kl=lambda_kl, lambda_couple=m['lambda_couple'],
                     lambda_seq_couple=m['lambda_seq_couple'], euclidean_dist=m['euclidean_dist'],
-                    lr=m['lr'], clip_norm=m['clip_norm'], lambda_fb=m.get('lambda_fb', 0.0))
+                    lr=m['lr'], clip_norm=m['clip_norm'], lambda_fb=m.get('lambda_fb', 0.0),
+                    lambda_bow=m.get('lambda_BoW', 0.0))
+
+    def none_grad_keys(self, it):
+        """state_dict keys whose gradient is None in the reference at recorded iteration `it` (the BoW head while the
+        bag-of-words term is left out of the total, CV/Experiment.py:711-713)."""
+        per = self.meta.get('none_grad_keys_per_step')
+        return per[it] if per else self.meta['none_grad_keys']
 
     def kl_per_sentence(self, prefix):
         """The KL term of every sentence as the recorded model's training loop forms it from the recorded

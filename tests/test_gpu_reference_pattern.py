@@ -28,7 +28,7 @@ IMQ_SCALES = (.1, .2, .5, 1., 2., 5., 10.)
 
 CASES = ['text_vae-couple_gru_tiny', 'text_vae-couple_lstm_tiny', 'text_vae-couple_lstm_mid',
          'text_vae-couple-euclid_gru_tiny', 'text_vae_gru_tiny', 'dialog_cvae-couple_gru_tiny',
-         'dialog_cvae-couple_lstm_tiny', 'dialog_cvae_gru_tiny']
+         'dialog_cvae-couple_lstm_tiny', 'dialog_cvae_gru_tiny', 'text_vae-couple-bow_gru_tiny', 'text_vae-bow_lstm_tiny']
 
 
 @pytest.fixture(scope='module')
@@ -96,9 +96,9 @@ def test_reference_training_loop_pattern(dev, name):
                 out = model(go=b['go'], sent_len=b['len'], bare=b['bare'])
                 eos = b['eos']
                 if couple:
-                    logits, post, _, _, logits_c, init, init_c = out
+                    logits, post, _, bow_logits, logits_c, init, init_c = out
                 else:
-                    logits, post, _, _ = out
+                    logits, post, _, bow_logits = out
                 prior = torch.distributions.Normal(torch.zeros(m['Z'], device=dev), torch.ones(m['Z'], device=dev))
             seq = model.criterionSeq(logits, eos, keep_batch=True).mean(0)
             kl_elem = torch.distributions.kl_divergence(post, prior)
@@ -116,6 +116,12 @@ def test_reference_training_loop_pattern(dev, name):
                         C = 2. * m['Z'] * s
                         cpl = cpl - C / (C + euc)
                 tot = tot + seq_c * m['lambda_seq_couple'] + m['lambda_couple'] * cpl.mean(0)
+            if m.get('lambda_BoW', 0.0) > 0:          # CV/Experiment.py:703-706, 711-713
+                bow_logits = bow_logits.unsqueeze(1).expand(-1, b['bare'].shape[1], -1)
+                bow_sum = model.criterionSeq(bow_logits, b['bare'], keep_batch=True)
+                assert rel(bow_sum, g.t(p + 'bow_sum_per_sent')) < LOSS_TOL
+                if lam > 1e-5:
+                    tot = tot + m['lambda_BoW'] * (bow_sum / b['len'].float()).mean(0)
             optim.zero_grad()
             tot.backward()
             # ---- against the reference's recorded values
@@ -126,7 +132,7 @@ def test_reference_training_loop_pattern(dev, name):
                 assert rel(euc, g.t(p + 'euc')) < LOSS_TOL
             assert close(tot, g.np(p + 'tot'), LOSS_TOL)
             for k in m['state_keys']:
-                if k in m['none_grad_keys']:
+                if k in g.none_grad_keys(it):
                     assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
                 else:
                     assert rel(sd[k].grad, g.t(p + 'grad/' + k)) < GRAD_TOL, (it, k)
