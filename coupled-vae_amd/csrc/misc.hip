@@ -273,28 +273,30 @@ int launch_zero(float* p, long n, hipStream_t s) {
 __global__ __launch_bounds__(256) void zero_multi_kernel(ZeroList z) {
   float* p = z.p[blockIdx.y];
   const long n = z.n[blockIdx.y];
+  const float f = __uint_as_float(z.bits[blockIdx.y]);
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
     const long n4 = n / 4;
     float4* p4 = reinterpret_cast<float4*>(p);
-    for (long k = i; k < n4; k += stride) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long k = 4 * n4 + i; k < n; k += stride) p[k] = 0.f;
+    for (long k = i; k < n4; k += stride) p4[k] = make_float4(f, f, f, f);
+    for (long k = 4 * n4 + i; k < n; k += stride) p[k] = f;
   } else {
-    for (long k = i; k < n; k += stride) p[k] = 0.f;
+    for (long k = i; k < n; k += stride) p[k] = f;
   }
 }
-void ZeroBatch::add(float* p, long n) {
+void ZeroBatch::add(float* p, long n) { add_fill(p, n, 0u); }
+void ZeroBatch::add_fill(float* p, long n, unsigned bits) {
   if (n <= 0 || !p) return;
   if (z.count == ZeroList::MAX) flush_status |= flush();
-  z.p[z.count] = p; z.n[z.count] = n; ++z.count;
+  z.p[z.count] = p; z.n[z.count] = n; z.bits[z.count] = bits; ++z.count;
 }
 int ZeroBatch::flush() {
   if (z.count == 0) return flush_status;
   long most = 0;
   for (int i = 0; i < z.count; ++i) most = z.n[i] > most ? z.n[i] : most;
   long blocks = (most / 4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks, z.count), dim3(256), 0, s, z);
   z.count = 0;

@@ -24,13 +24,14 @@ int launch_copy_cols(int R, int C, const float* src, long lds, int soff, float* 
 int launch_targets_tm(const int64_t* eos, int B, int T, int R, int64_t* out, hipStream_t s);
 int launch_targets_sm(const int64_t* eos, int B, int T, int K, int64_t* out, hipStream_t s);
 // zero several buffers with one launch: add(...) then flush() (also flushes when full)
-struct ZeroList { static constexpr int MAX = 8; float* p[MAX]; long n[MAX]; int count; };
+struct ZeroList { static constexpr int MAX = 8; float* p[MAX]; long n[MAX]; unsigned bits[MAX]; int count; };
 struct ZeroBatch {
   ZeroList z = {};
   hipStream_t s;
   int flush_status = 0;
   explicit ZeroBatch(hipStream_t stream) : s(stream) {}
   void add(float* p, long n);
+  void add_fill(float* p, long n, unsigned bits);      // every 4-byte word = bits (add = add_fill(.., 0))
   int flush();
 };
 bool linear_bwd_small_supported(int M, int N, int K);

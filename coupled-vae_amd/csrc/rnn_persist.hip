@@ -52,6 +52,7 @@ struct PSeqF {
 struct PFwdArgs {
   PSeqF q[SKINNY_MAX_BATCH];
   int T, R, H, nw;                   // nw: waves that take part in the K split (H / nw multiple of 16)
+  int poll_delay, poll_delay_cell;   // in-band form: s_sleep(1) periods before a step's first poll (other / cell waves)
   unsigned* flags;                   // [ns][P_MAXB] epoch flags, zero at launch
   int* status;
   unsigned long long* stamps;
@@ -349,6 +350,268 @@ __global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_kernel(PFwdArgs p) 
       }
     }
   }
+  if (stamp_on)
+    for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
+}
+
+// ------------------------------------------------------------------------- forward, in-band hand-off
+// The same step as rnn_fwd_persist_kernel<CELL, true> (bf16x3 product) with ONE memory round trip per step instead
+// of two.  The flag form serialises  payload stores -> drain -> flag store -> [flag poll] -> barrier -> payload load;
+// here the payload is its own flag: before the launch every slot of hs the kernel is going to write is filled with
+// the word P_SENT (0xFFFFFFFF, a NaN pattern arithmetic never produces: AMD's default NaN is 0x7FC00000), the cell
+// threads store h with 16-byte write-through (sc1) stores and go on, and every consuming wave polls the very 16-byte
+// pieces it multiplies (volatile sc1 buffer loads, so the loop re-reads memory) until none of their words is the
+// sentinel.  A 16-byte piece is written by ONE lane's one store; a piece observed half-written would show a
+// sentinel word and simply be read again.  Only pieces still missing are re-read.  No flag words, no drain, no
+// publish barrier; one workgroup barrier per step (the partial sums go through a double-buffered LDS tile).
+// Spins are bounded as before (status word, grid drains).
+// Column c of the block's 16 MFMA columns is (unit c >> 2, gate c & 3) (a GRU leaves gate 3 empty), so a cell thread
+// reads its unit's gates of one partial tile with ONE ds_read_b128.
+constexpr unsigned P_SENT = 0xFFFFFFFFu;
+constexpr int P_AUX_SC1_VOLATILE = (int)(0x80000000u | (unsigned)P_AUX_SC1);   // bit 31: volatile (compiler side)
+
+__device__ __forceinline__ u32x4v ld16_sc1_poll(__amdgpu_buffer_rsrc_t r, long float_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, P_AUX_SC1_VOLATILE);
+}
+__device__ __forceinline__ bool piece_landed(u32x4v v) {
+  return v[0] != P_SENT && v[1] != P_SENT && v[2] != P_SENT && v[3] != P_SENT;
+}
+
+// Work split (HU, RG): a sequence's R <= 32 rows are cut into RG groups of RPG = 32 / RG rows, its H units into
+// H / HU slices; a block owns (row group, unit slice) and exchanges h only with the H / HU blocks of its row group
+// (rows never interact).  HU = 4, RG = 1 is the split of the flag kernel: every block pulls the whole 32 x H state
+// (64 KB at H = 512) through its CU's memory pipe each step and every line is read by H / 4 CUs.  HU = 8 / RG = 2
+// and HU = 16 / RG = 4 keep the block count and halve / quarter both (a 16-row MFMA fragment is the minimum, so
+// RG = 4 multiplies 8 live rows in a 16-row fragment).
+// value of lane + D of the same 4-lane quad (D = 1..3; wraps inside the quad): one DPP move, no LDS round trip
+template <int D>
+__device__ __forceinline__ float quad_down(float v) {
+  constexpr int ctrl = ((0 + D) & 3) | (((1 + D) & 3) << 2) | (((2 + D) & 3) << 4) | (((3 + D) & 3) << 6);   // quad_perm
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+
+template <int CELL, int HU, int RG>
+__global__ __launch_bounds__(P_THREADS) void rnn_fwd_persist_tag_kernel(PFwdArgs p) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  constexpr int RPG = 32 / RG;                         // rows of a group (32, 16, 8)
+  constexpr int NF = RPG >= 16 ? RPG / 16 : 1;         // 16-row MFMA fragments
+  constexpr int CF = HU / 4;                           // 16-column fragments: (4 units x 4 gates) each
+  constexpr int NP = 2 * NF;                           // 16-byte pieces of h a lane multiplies
+  constexpr int LDR = 16 * CF;                         // floats per row of a partial tile
+  constexpr int TILE = RPG * LDR;                      // one wave's partial tile (512 floats for every (HU, RG))
+  extern __shared__ __attribute__((aligned(16))) float redd[];       // [2][16 waves][RPG rows][LDR]
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const PSeqF& q = p.q[blockIdx.y];
+  const int H = p.H, R = p.R, T = p.T;
+  const int nslice = H / HU;
+  const int u0 = (blockIdx.x % nslice) * HU;
+  const int row0 = (blockIdx.x / nslice) * RPG;
+  const int NW = H / 32;                               // one 32-wide bf16 MFMA K block per wave
+  const long RH = (long)R * H;
+  const int GH = G * H;
+  const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const __amdgpu_buffer_rsrc_t rs_hs = make_rsrc(q.hs);
+  if (tid == 0) s_abort = 0;
+  if (row0 >= R) return;                               // a row group past the batch: nothing to do, nobody waits for it
+
+  // W_hh fragments (B operand: lane = column l15 = (unit & 3) * 4 + gate of fragment c, k = wave*32 + 8*kq .. + 7),
+  // split once, resident for all T steps
+  bf16x8p wbh[CF], wbl[CF];
+  const int kbase = wave * 32 + kq * 8;
+#pragma unroll
+  for (int c = 0; c < CF; ++c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wbh[c][e] = (__bf16)0.f; wbl[c][e] = (__bf16)0.f; }
+    if (wave < NW && (l15 & 3) < G) {
+      const float* wr = q.W_hh + (long)((l15 & 3) * H + u0 + 4 * c + (l15 >> 2)) * H + kbase;
+      const float4 v0 = *reinterpret_cast<const float4*>(wr), v1 = *reinterpret_cast<const float4*>(wr + 4);
+      const f32x8p v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      wbh[c] = __builtin_convertvector(v, bf16x8p);
+      wbl[c] = __builtin_convertvector(v - __builtin_convertvector(wbh[c], f32x8p), bf16x8p);
+    }
+  }
+
+  // cell threads: (row, unit) = (tid / HU, tid % HU) of the block's RPG x HU = 128 pairs; state in registers
+  const bool cellt = tid < 128;
+  const int clr = tid / HU, cu = tid % HU;             // row within the group, unit within the slice
+  const int crow = row0 + clr, cn = u0 + cu;
+  const bool crv = cellt && crow < R;
+  float hprev = 0.f, cprev = 0.f, bh[G], xa[G];
+  int64_t len = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) { bh[g] = 0.f; xa[g] = 0.f; }
+  const int init_slot = q.reverse ? T : 0;
+  if (crv) {
+    hprev = q.hs[init_slot * RH + (long)crow * H + cn];
+    if (CELL == CELL_LSTM) cprev = q.cs[init_slot * RH + (long)crow * H + cn];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bh[g] = q.b_hh[g * H + cn];
+      if (q.xadd) xa[g] = q.xadd[(long)crow * GH + g * H + cn];
+    }
+    len = q.lengths ? q.lengths[crow] : (int64_t)T;
+  }
+  const int xrow = crv ? crow % q.xmod : 0;
+  // the pieces of h_{t-1} this lane multiplies: piece 2f + j = row row0 + 16f + l15, k = kbase + 4j .. + 3
+  unsigned mine = 0;
+  if (wave < NW) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+      if (16 * f + l15 < RPG && row0 + 16 * f + l15 < R) mine |= 3u << (2 * f);
+  }
+  const long poff = (long)(row0 + l15) * H + kbase;
+  __syncthreads();
+
+  // c and the gates of a step (saved for backward: nobody in this launch reads them) leave AFTER the next step's
+  // poll loads have been issued: on the cell waves they would otherwise sit in the memory pipe in front of them
+  f32x4v pend_c = {0.f, 0.f, 0.f, 0.f}, pend_g[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pend_g[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  long pend_co = -1, pend_go = 0;
+  auto flush_pending = [&]() {
+    if (pend_co >= 0) {
+      if (CELL == CELL_LSTM) *reinterpret_cast<f32x4v*>(q.cs + pend_co) = pend_c;
+      if (q.gates) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4v*>(q.gates + pend_go + g * H) = pend_g[g];
+      }
+    }
+  };
+
+  for (int i = 0; i < T; ++i) {
+    const int t = q.reverse ? T - 1 - i : i;
+    const int in_slot = q.reverse ? t + 1 : t, out_slot = q.reverse ? t : t + 1;
+    float* red = redd + (i & 1) * (16 * TILE);
+    P_STAMP(0);
+
+    u32x4v a[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) a[j] = u32x4v{0u, 0u, 0u, 0u};
+    unsigned need = mine;
+    const long base = in_slot * RH + poff;
+    if (wave < NW) {
+      // h_{t-1} cannot be there before the producers' cell phase and their stores' flight: polling earlier only
+      // queues loads in front of this CU's own h stores (measured: the step got 25 % longer)
+      if (i > 0)
+        for (int k = (wave < 2 ? p.poll_delay_cell : p.poll_delay); k > 0; --k) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        if (need & (1u << j)) a[j] = ld16_sc1_poll(rs_hs, base + (long)(j >> 1) * 16 * H + 4 * (j & 1));
+    }
+    // behind the poll loads in the memory pipe: the previous step's c / gates, and this step's x-side
+    // pre-activations (independent of the recurrence, consumed after the barrier)
+    float x[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) x[g] = 0.f;
+    if (cellt) {
+      flush_pending();
+      pend_co = -1;
+      if (crv) {
+        const float* xp = q.xproj + ((long)t * q.xmod + xrow) * GH + cn;
+#pragma unroll
+        for (int g = 0; g < G; ++g) x[g] = xp[g * H];
+      }
+    }
+    if (wave < NW) {
+      unsigned spins = 0;
+      for (;;) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+          if ((need & (1u << j)) && piece_landed(a[j])) need &= ~(1u << j);
+        if (!__any(need != 0u)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > P_SPIN_LIMIT) {
+          if (lane == 0) {
+            __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped word
+            s_abort = 1;
+          }
+          break;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+          if (need & (1u << j)) a[j] = ld16_sc1_poll(rs_hs, base + (long)(j >> 1) * 16 * H + 4 * (j & 1));
+      }
+      P_STAMP(1);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const f32x4v lo4 = __builtin_bit_cast(f32x4v, a[2 * f]), hi4 = __builtin_bit_cast(f32x4v, a[2 * f + 1]);
+        const f32x8p v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        const bf16x8p ah = __builtin_convertvector(v, bf16x8p);
+        const bf16x8p al = __builtin_convertvector(v - __builtin_convertvector(ah, f32x8p), bf16x8p);
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+          f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wbh[c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wbl[c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wbh[c], acc, 0, 0, 0);
+          // C layout of 16x16x32: acc[r] = (row 16f + 4*kq + r, column l15)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * f + 4 * kq + r < RPG) red[wave * TILE + (16 * f + 4 * kq + r) * LDR + 16 * c + l15] = acc[r];
+        }
+      }
+    }
+    P_STAMP(2);
+    __syncthreads();
+    if (s_abort) return;                                   // uniform: written before the barrier
+    P_STAMP(3);
+
+    if (cellt) {
+      f32x4v s4 = {0.f, 0.f, 0.f, 0.f};
+      const float* rp = red + clr * LDR + (cu >> 2) * 16 + (cu & 3) * 4;
+      for (int wv = 0; wv < NW; ++wv) s4 += *reinterpret_cast<const f32x4v*>(rp + wv * TILE);
+      float s[4] = {s4[0], s4[1], s4[2], s4[3]};
+      P_STAMP(6);
+      float hnew = hprev, cnew = cprev, g0, g1, g2, g3;
+      const bool live = (int64_t)t < len;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { s[g] += bh[g]; x[g] += xa[g]; }
+      if (crv) {
+        if constexpr (CELL == CELL_GRU) {
+          const float rg = fast_sigmoid(x[0] + s[0]);
+          const float zg = fast_sigmoid(x[1] + s[1]);
+          const float nn = fast_tanh(x[2] + rg * s[2]);
+          if (live) hnew = (1.f - zg) * nn + zg * hprev;
+          g0 = rg; g1 = zg; g2 = nn; g3 = s[2];
+        } else {
+          const float ig = fast_sigmoid(x[0] + s[0]);
+          const float fg = fast_sigmoid(x[1] + s[1]);
+          const float gg = fast_tanh(x[2] + s[2]);
+          const float og = fast_sigmoid(x[3] + s[3]);
+          const float cc = fg * cprev + ig * gg;
+          if (live) { hnew = og * fast_tanh(cc); cnew = cc; }
+          g0 = ig; g1 = fg; g2 = gg; g3 = og;
+        }
+      } else {
+        g0 = g1 = g2 = g3 = 0.f;
+      }
+      hprev = hnew; cprev = cnew;
+      P_STAMP(7);
+      // the hand-off payload first and alone: 4 units of a row in the lane of the first of them (quad-local
+      // data-parallel moves, no LDS round trip), one 16-byte store
+      f32x4v hv;
+      hv[0] = hnew; hv[1] = quad_down<1>(hnew); hv[2] = quad_down<2>(hnew); hv[3] = quad_down<3>(hnew);
+      if (crv && (cu & 3) == 0) st16_sc1(rs_hs, out_slot * RH + (long)crow * H + cn, hv);
+      P_STAMP(4);
+      pend_c[0] = cnew; pend_c[1] = quad_down<1>(cnew); pend_c[2] = quad_down<2>(cnew); pend_c[3] = quad_down<3>(cnew);
+      const float sg[4] = {g0, g1, g2, g3};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pend_g[g][0] = sg[g]; pend_g[g][1] = quad_down<1>(sg[g]); pend_g[g][2] = quad_down<2>(sg[g]);
+        pend_g[g][3] = quad_down<3>(sg[g]);
+      }
+      if (crv && (cu & 3) == 0) {
+        pend_co = out_slot * RH + (long)crow * H + cn;
+        pend_go = ((long)t * R + crow) * 4 * H + cn;
+      }
+    }
+    P_STAMP(5);
+  }
+  if (cellt) flush_pending();
   if (stamp_on)
     for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
 }
@@ -704,16 +967,33 @@ bool rnn_persist_supported(int cell, int T, int R, int H, int ns) {
   return H / P_HU <= P_MAXB && (H / P_HU) * ns <= cu_count();
 }
 
+// CVAE_PERSIST_TAG=0: the flag + payload hand-off (two round trips per step) instead of the in-band one
+static bool persist_tag_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CVAE_PERSIST_TAG");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
 int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb) {
   unsigned* sync = nullptr;
   int* status = nullptr;
   CVAE_TRY(persist_sync(s, &sync, &status));
-  if (zb) {
-    zb->add(reinterpret_cast<float*>(sync), P_FLAG_WORDS);
-    CVAE_TRY(zb->flush());
+  const bool tag = persist_tag_enabled() && split_bf16_enabled() && a[0].H % 32 == 0 && a[0].H / 32 <= 16;
+  ZeroBatch local(s);
+  ZeroBatch* z = zb ? zb : &local;
+  if (tag) {
+    // every slot the kernel will write starts as the sentinel (the initial slot holds the initial state)
+    for (int k = 0; k < ns; ++k) {
+      const long RH = (long)a[k].R * a[k].H;
+      z->add_fill(a[k].hs + (a[k].reverse ? 0 : RH), (long)a[k].T * RH, P_SENT);
+    }
   } else {
-    CVAE_TRY(launch_zero(reinterpret_cast<float*>(sync), P_FLAG_WORDS, s));
+    z->add(reinterpret_cast<float*>(sync), P_FLAG_WORDS);
   }
+  CVAE_TRY(z->flush());
   PFwdArgs p = {};
   p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
   p.nw = 0;
@@ -737,7 +1017,46 @@ int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch
   }
   const dim3 grid(p.H / P_HU, ns), block(P_THREADS);
   ProfScope prof(PK_RNN_PERSIST, s, 2.0 * ns * p.T * p.R * (a[0].cell == CELL_GRU ? 3.0 : 4.0) * p.H * p.H);
-  if (bf) {
+  if (tag) {
+    static int pd = -1, pdc = -1, split = -1;
+    if (pd < 0) {
+      const char* e = getenv("CVAE_PERSIST_POLL_DELAY");
+      pd = e ? atoi(e) : 16;
+      e = getenv("CVAE_PERSIST_POLL_DELAY_CELL");
+      pdc = e ? atoi(e) : 4;
+      e = getenv("CVAE_PERSIST_FWD_SPLIT");              // row groups per sequence: 1 (HU 4), 2 (HU 8), 4 (HU 16)
+      split = e ? atoi(e) : 4;
+      if (split != 1 && split != 2) split = 4;
+    }
+    p.poll_delay = pd; p.poll_delay_cell = pdc;
+    int rg = split;
+    while (rg > 1 && p.H % (4 * rg) != 0) rg >>= 1;
+    constexpr size_t lds = 2 * 16 * 512 * sizeof(float);               // 64 KB: double-buffered partial tiles
+    static bool tag_attr_set = false;
+    const void* fns[6] = {reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_GRU, 4, 1>),
+                          reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_LSTM, 4, 1>),
+                          reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_GRU, 8, 2>),
+                          reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_LSTM, 8, 2>),
+                          reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_GRU, 16, 4>),
+                          reinterpret_cast<const void*>(&rnn_fwd_persist_tag_kernel<CELL_LSTM, 16, 4>)};
+    if (!tag_attr_set) {
+      for (const void* f : fns)
+        CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "persist fwd LDS attribute"));
+      tag_attr_set = true;
+    }
+    const bool gru = a[0].cell == CELL_GRU;
+    if (rg == 4) {
+      if (gru) hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_GRU, 16, 4>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_LSTM, 16, 4>), grid, block, lds, s, p);
+    } else if (rg == 2) {
+      if (gru) hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_GRU, 8, 2>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_LSTM, 8, 2>), grid, block, lds, s, p);
+    } else {
+      if (gru) hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_GRU, 4, 1>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((rnn_fwd_persist_tag_kernel<CELL_LSTM, 4, 1>), grid, block, lds, s, p);
+    }
+  } else if (bf) {
     if (a[0].cell == CELL_GRU) hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_GRU, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((rnn_fwd_persist_kernel<CELL_LSTM, true>), grid, block, 0, s, p);
   } else {
@@ -851,7 +1170,7 @@ int persist_status_and_clear() {
     unsigned long long acc[16];
     if (hipMemcpy(acc, persist_stamps(), sizeof(acc), hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "[cvae persist stamps, cycles of block (0,0)] loop-top->wait %llu | wait %llu | load+mfma %llu | reduce %llu | "
-              "cell+stores %llu | drain+flag %llu   (bwd: top | wait | gather | cell | product+publish stores | drain+flag)\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+              "cell+stores %llu | drain+flag %llu | [6] %llu | [7] %llu  (bwd: top | wait | gather | cell | product+publish stores | drain+flag)\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
       if (hipMemset(persist_stamps(), 0, sizeof(acc)) != hipSuccess) return -1;
     }
   }
