@@ -73,6 +73,7 @@ struct PBwdArgs {
   int* status;
   unsigned long long* stamps;
   float* exch;                       // [ns][2][nb][nb][32][4] partial-sum exchange
+  int poll_delay;                    // in-band form: s_sleep(1) periods before a step's first poll
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -923,6 +924,278 @@ __global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_kernel(PBwdArgs p) 
     for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
 }
 
+// ------------------------------------------------------------------------ backward, in-band hand-off
+// The backward step of rnn_bwd_persist_kernel<CELL, HU, true> (bf16x6 product, reduce-scatter of the partial dh)
+// with the forward kernel's two changes:
+//   * rows x units work split: a block owns HU units of ONE of RG row groups (RPG = 32 / RG rows; rows never
+//     interact), so it publishes an RPG x H partial and gathers RPG x HU x (H / HU) floats per step: 64 KB each way
+//     for (HU 8, RG 1), 32 KB for (8, 2), 16 KB for (16, 4), and exchanges with H / HU blocks only;
+//   * in-band hand-off: the exchange buffer is armed with P_SENT; a gathering thread polls the 16-byte pieces it
+//     sums (volatile sc1 loads) until they hold no sentinel word, and re-arms them (sc1 stores of the sentinel) as
+//     soon as it has them.  A piece is rewritten by its producer two steps later at the earliest, behind a chain of
+//     hand-offs that starts after this thread's next vmcnt(0) wait, which every wave makes before it publishes
+//     again: the re-arm store has completed before that.  No flags, no drain, no publish barrier.
+// The pieces a step publishes are known on both sides (row bound from zero_after / lengths), as before.
+template <int CELL, int HU, int RG>
+__global__ __launch_bounds__(P_THREADS) void rnn_bwd_persist_tag_kernel(PBwdArgs p) {
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;
+  constexpr int NC = HU * G;                         // live K of this block's slice
+  constexpr int NKB = (NC + 31) / 32;                // 32-wide MFMA K blocks
+  constexpr int DGS_LD = 32 * NKB + 8;               // bf16 per dG row in LDS
+  constexpr int RPG = 32 / RG;                       // rows of a group
+  constexpr int NF = RPG >= 16 ? RPG / 16 : 1;       // 16-row MFMA fragments
+  constexpr int MR = 16 * NF;                        // rows of the A operand in LDS (padding rows stay zero)
+  constexpr int GPR = HU / 4;                        // 16-byte pieces per (row, destination)
+  constexpr int PIECE = RPG * HU;                    // floats one block sends to one destination per step
+  static_assert(RPG * GPR == 32, "a wave's 64 lanes cover two sources x 32 (row, piece) pairs");
+  extern __shared__ __attribute__((aligned(16))) float dyn[];      // tile[RPG][H + 4] | red[16 waves][32][4]
+  __shared__ __attribute__((aligned(16))) __bf16 dGs[3][MR * DGS_LD];           // hi | mid | lo, [row][k]
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const PSeqB& q = p.q[blockIdx.y];
+  const int H = p.H, R = p.R, T = p.T;
+  const int nsl = H / HU;
+  const int sl = blockIdx.x % nsl, rgi = blockIdx.x / nsl;
+  const int GH = G * H, LDT = H + 4;
+  const int u0 = sl * HU, row0 = rgi * RPG;
+  const long RH = (long)R * H;
+  float* tile = dyn;
+  float* red = dyn + RPG * LDT;
+  const bool stamp_on = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  unsigned long long tprev_ = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned sacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float* dgh_base = q.dgh ? q.dgh : q.dgx;
+  // exchange of this (sequence, row group): [parity][dest slice][src slice][RPG][HU] floats
+  const long ex_par = (long)nsl * nsl * PIECE;
+  const __amdgpu_buffer_rsrc_t rs_ex = make_rsrc(p.exch + ((size_t)blockIdx.y * RG + rgi) * 2 * ex_par);
+  if (tid == 0) s_abort = 0;
+  if (row0 >= R) return;                               // a row group past the batch
+  for (int i = tid; i < 3 * MR * DGS_LD; i += P_THREADS) (&dGs[0][0])[i] = (__bf16)0.f;
+
+  // W_hh[gate rows of the slice, :] as B fragments: wave w owns output column fragments w, w + 16
+  const int nfr = H / 16;
+  bf16x8p wb[2][NKB][3];                               // lane (n = l15, kq) holds k = 32*kb + 8*kq .. + 7 (zero past NC)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nf = wave + 16 * j;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * kb + 8 * kq + e;
+        float v = 0.f;
+        if (nf < nfr && k < NC) v = q.W_hh[(long)((k % G) * H + u0 + k / G) * H + 16 * nf + l15];
+        __bf16 h_, m_, l_;
+        split3(v, h_, m_, l_);
+        wb[j][kb][0][e] = h_; wb[j][kb][1][e] = m_; wb[j][kb][2][e] = l_;
+      }
+  }
+
+  const bool cellt = tid < RPG * HU;                   // 128 threads
+  const int clr = tid / HU, cu = tid % HU;
+  const int crow = row0 + clr, cn = u0 + cu;
+  const bool crv = cellt && crow < R;
+  float dh_carry = 0.f, dc = 0.f;
+  int64_t len = 0;
+  if (crv) {
+    if (q.dh_last) dh_carry = q.dh_last[(long)crow * H + cn];
+    if (CELL == CELL_LSTM && q.dc_last) dc = q.dc_last[(long)crow * H + cn];
+    len = q.lengths ? q.lengths[crow] : (int64_t)T;
+  }
+  // bound(t) = 1 + the highest row of the BATCH whose gradient is still non-zero at step t (see the flag kernel)
+  const int64_t za = (lane < R) ? (q.zero_after ? q.zero_after[lane] : (q.lengths ? q.lengths[lane] : (int64_t)T)) : 0;
+  auto row_bound = [&](int t) -> int {
+    const unsigned long long m = __ballot(lane < 32 && (int64_t)t < za);
+    return m ? 64 - __clzll(m) : 0;
+  };
+  int rb_prev = 0;                                      // bound of the partials published last
+  __syncthreads();
+
+  // 16-byte piece gq of the block's nsl x RPG x HU incoming (or outgoing) floats: (slice gq / 32, row (gq / GPR) % RPG,
+  // part gq % GPR); a thread's pieces gq = tid + 1024 j share row and part
+  const int grow = (tid / GPR) % RPG, gpart = tid % GPR;
+  const int ngran = nsl * 32;
+  constexpr int MAXJ = 4;                               // nsl <= 128
+
+  // sum over all source slices of their partial for (clr, cu); parity = buffer to read.  Uniform false on timeout.
+  auto gather = [&](int parity, int bound, float& tot) -> bool {
+    const long base = (long)parity * ex_par + (long)sl * nsl * PIECE;
+    u32x4v v[MAXJ];
+    unsigned need = 0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      v[j] = u32x4v{0u, 0u, 0u, 0u};
+      if (tid + P_THREADS * j < ngran && row0 + grow < bound) need |= 1u << j;
+    }
+    const unsigned mine = need;
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+        if (need & (1u << j)) v[j] = ld16_sc1_poll(rs_ex, base + (long)(tid + P_THREADS * j) * 4);
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+        if ((need & (1u << j)) && piece_landed(v[j])) need &= ~(1u << j);
+      if (!__any(need != 0u)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > P_SPIN_LIMIT) {
+        if (lane == 0) {
+          __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_abort = 1;
+        }
+        break;
+      }
+    }
+    // re-arm what was taken (its producer writes it again two steps from now)
+    const f32x4v sent = __builtin_bit_cast(f32x4v, u32x4v{P_SENT, P_SENT, P_SENT, P_SENT});
+    f32x4v sum = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (mine & (1u << j)) {
+        st16_sc1(rs_ex, base + (long)(tid + P_THREADS * j) * 4, sent);
+        sum += __builtin_bit_cast(f32x4v, v[j]);
+      }
+    // lanes l and l + 32 hold the same (row, part) of two sources
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], 32, 64);
+    if (lane < 32) *reinterpret_cast<f32x4v*>(red + (size_t)(wave * 32 + lane) * 4) = sum;
+    __syncthreads();
+    if (s_abort) return false;
+    tot = 0.f;
+    if (cellt) {
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tot += red[(size_t)(w * 32 + clr * GPR + (cu >> 2)) * 4 + (cu & 3)];
+    }
+    return true;
+  };
+
+  for (int i = T - 1; i >= 0; --i) {
+    const int t = q.reverse ? T - 1 - i : i;
+    const int in_slot = q.reverse ? t + 1 : t, out_slot = q.reverse ? t : t + 1;
+    // saved tensors of step t for this (row, unit): independent of the recurrence
+    float gl[4] = {0.f, 0.f, 0.f, 0.f}, hin = 0.f, cin = 0.f, cout = 0.f, dhs_t = 0.f;
+    if (crv) {
+      const float* gp = q.gates + ((long)t * R + crow) * 4 * H + cn;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gl[g] = gp[g * H];
+      hin = q.hs[in_slot * RH + (long)crow * H + cn];
+      if (CELL == CELL_LSTM) {
+        cin = q.cs[in_slot * RH + (long)crow * H + cn];
+        cout = q.cs[out_slot * RH + (long)crow * H + cn];
+      }
+      if (q.dhs) dhs_t = q.dhs[(long)t * RH + (long)crow * H + cn];
+    }
+    float part = 0.f;
+    P_STAMP(0);
+    if (i < T - 1) {
+      for (int k = p.poll_delay; k > 0; --k) __builtin_amdgcn_s_sleep(1);
+      if (!gather((T - 1 - i) & 1, rb_prev, part)) return;
+      P_STAMP(2);
+    }
+    float ox[4] = {0.f, 0.f, 0.f, 0.f}, oh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cellt) {
+      if (crv) {
+        const bool live = (int64_t)t < len;
+        const float dh = dh_carry + dhs_t + part;
+        dh_carry = cell_bwd_point<CELL>(live, dh, dc, gl, 1, hin, cin, cout, ox, CELL == CELL_GRU ? oh : nullptr);
+      }
+      // A operand of the product: the h-side gradients, split once
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float v = (CELL == CELL_GRU) ? oh[g] : ox[g];
+        __bf16 h_, m_, l_;
+        split3(v, h_, m_, l_);
+        const int o = clr * DGS_LD + cu * G + g;
+        dGs[0][o] = h_; dGs[1][o] = m_; dGs[2][o] = l_;
+      }
+    }
+    __syncthreads();
+    P_STAMP(3);
+    // product: the group's row fragment(s) x this wave's column fragments, K = NC
+    const int rb_cur = row_bound(t);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (rb_cur > row0 + 16 * f) {
+        bf16x8p a[NKB][3];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int tm = 0; tm < 3; ++tm)
+            a[kb][tm] = *reinterpret_cast<const bf16x8p*>(&dGs[tm][(16 * f + l15) * DGS_LD + 32 * kb + 8 * kq]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nf = wave + 16 * j;
+          if (nf < nfr) {
+            // small terms first: mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi
+            f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], wb[j][kb][1], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][2], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][2], wb[j][kb][0], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][1], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][1], wb[j][kb][0], acc, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][0], wb[j][kb][0], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * f + 4 * kq + r < RPG) tile[(16 * f + 4 * kq + r) * LDT + 16 * nf + l15] = acc[r];
+          }
+        }
+      }
+    }
+    // every re-arm store of this step's gather has completed before anything new is published (see the header)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // publish, destination-major: piece (dest d, row r, part) = tile[r][HU*d + 4*part ..] -> ex[parity][d][me][r][4*part ..]
+    {
+      const long wbase = (long)((T - i) & 1) * ex_par + (long)sl * PIECE;
+      rb_prev = rb_cur;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int gq = tid + P_THREADS * j;
+        if (gq < ngran && row0 + grow < rb_prev) {
+          const int d = gq / 32;
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + grow * LDT + HU * d + 4 * gpart);
+          st16_sc1(rs_ex, wbase + ((long)d * nsl) * PIECE + (long)grow * HU + 4 * gpart, v);
+        }
+      }
+    }
+    P_STAMP(4);
+    // global copies of dG for the weight gradients (nobody in this launch reads them): behind the hand-off stores
+    if (cellt) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4v vx, vh;
+        vx[0] = ox[g]; vx[1] = quad_down<1>(ox[g]); vx[2] = quad_down<2>(ox[g]); vx[3] = quad_down<3>(ox[g]);
+        if (CELL == CELL_GRU) { vh[0] = oh[g]; vh[1] = quad_down<1>(oh[g]); vh[2] = quad_down<2>(oh[g]); vh[3] = quad_down<3>(oh[g]); }
+        if (crv && (cu & 3) == 0) {
+          const long o = ((long)t * R + crow) * GH + g * H + cn;
+          *reinterpret_cast<f32x4v*>(q.dgx + o) = vx;
+          if (CELL == CELL_GRU) *reinterpret_cast<f32x4v*>(dgh_base + o) = vh;
+          else if (q.dgx != dgh_base) *reinterpret_cast<f32x4v*>(dgh_base + o) = vx;
+        }
+      }
+    }
+    P_STAMP(5);
+  }
+  // gradient wrt the initial state: carry + the last product
+  float part = 0.f;
+  if (T > 0) {
+    if (!gather(T & 1, rb_prev, part)) return;
+  }
+  if (crv) {
+    q.dh0[(long)crow * H + cn] = dh_carry + part;
+    if (CELL == CELL_LSTM) q.dc0[(long)crow * H + cn] = dc;
+  }
+  if (stamp_on)
+    for (int k = 0; k < 10; ++k) p.stamps[k] += sacc_[k];
+}
+
 // ------------------------------------------------------------------------------------ host side
 // library-owned sync words, one set per stream (lib_scratch): [SKINNY_MAX_BATCH][P_MAXB] epoch flags |
 // 16 spare words | 16 stamp accumulators | int64 [SKINNY_MAX_BATCH][32] zero_after scratch
@@ -1083,7 +1356,88 @@ static int persist_exch(hipStream_t s, long floats, float** out) {
   return 0;
 }
 
+// In-band backward (rnn_bwd_persist_tag_kernel): CVAE_PERSIST_TAG_BWD=0 selects the flag kernel;
+// CVAE_PERSIST_BWD_SPLIT = row groups per sequence: 1 (HU 4), 2 (HU 8), 4 (HU 16)
+static int launch_rnn_backward_persist_tag(const RnnBwd* a, int ns, hipStream_t s, int rg) {
+  unsigned* sync = nullptr;
+  int* status = nullptr;
+  CVAE_TRY(persist_sync(s, &sync, &status));
+  PBwdArgs p = {};
+  p.T = a[0].T; p.R = a[0].R; p.H = a[0].H;
+  p.flags = sync; p.status = status; p.stamps = persist_stamps();
+  const int G = a[0].cell == CELL_GRU ? 3 : 4;
+  const int hu = 4 * rg, nsl = p.H / hu;
+  const long ex_floats = (long)ns * 2 * nsl * nsl * 32 * hu;
+  CVAE_TRY(persist_exch(s, ex_floats, &p.exch));
+  {
+    ZeroBatch arm(s);                                     // every piece starts as "not there yet"
+    arm.add_fill(p.exch, ex_floats, P_SENT);
+    CVAE_TRY(arm.flush());
+  }
+  static int pd = -1;
+  if (pd < 0) { const char* e = getenv("CVAE_PERSIST_POLL_DELAY_BWD"); pd = e ? atoi(e) : 8; }
+  p.poll_delay = pd;
+  for (int k = 0; k < ns; ++k) {
+    const RnnBwd& r = a[k];
+    float* dgh = r.dgh ? r.dgh : r.dgx;
+    CVAE_REQUIRE((reinterpret_cast<uintptr_t>(r.dgx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dgh) & 15) == 0,
+                 "rnn_backward_persist: operands must be 16-byte aligned");
+    const int64_t* za = r.zero_after;
+    if (!za && !r.lengths && r.dhs && !r.dh_last && !r.dc_last && p.R <= 32) {
+      int64_t* zbuf = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(sync) + P_ZA_OFFSET) + (size_t)k * 32;
+      CVAE_TRY(launch_last_nonzero_step(p.T, p.R, p.H, r.dhs, zbuf, s));
+      za = zbuf;
+    }
+    p.q[k] = PSeqB{r.dhs, r.dh_last, r.dc_last, r.hs, r.cs, r.gates, r.W_hh, r.lengths, r.dgx, dgh, r.dh0, r.dc0, r.reverse, za};
+  }
+  const int rpg = 32 / rg;
+  const size_t lds = ((size_t)rpg * (p.H + 4) + 16 * 32 * 4) * sizeof(float);
+  const dim3 grid(nsl * rg, ns), block(P_THREADS);
+  const void* fns[6] = {reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_GRU, 4, 1>),
+                        reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_LSTM, 4, 1>),
+                        reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_GRU, 8, 2>),
+                        reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_LSTM, 8, 2>),
+                        reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_GRU, 16, 4>),
+                        reinterpret_cast<const void*>(&rnn_bwd_persist_tag_kernel<CELL_LSTM, 16, 4>)};
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* f : fns)
+      CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                         "persist bwd LDS attribute"));
+    attr_set = true;
+  }
+  ProfScope prof(PK_RNN_PERSIST_BWD, s, 2.0 * ns * p.T * p.R * G * p.H * p.H);
+  const bool gru = a[0].cell == CELL_GRU;
+  if (rg == 4) {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_GRU, 16, 4>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_LSTM, 16, 4>), grid, block, lds, s, p);
+  } else if (rg == 2) {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_GRU, 8, 2>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_LSTM, 8, 2>), grid, block, lds, s, p);
+  } else {
+    if (gru) hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_GRU, 4, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((rnn_bwd_persist_tag_kernel<CELL_LSTM, 4, 1>), grid, block, lds, s, p);
+  }
+  CVAE_LAUNCH_CHECK("rnn_bwd_persist_tag_kernel");
+  return 0;
+}
+
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s) {
+  {
+    static int tag = -1, split = 2;
+    if (tag < 0) {
+      const char* e = getenv("CVAE_PERSIST_TAG_BWD");
+      tag = (e && e[0] == '0') ? 0 : 1;
+      e = getenv("CVAE_PERSIST_BWD_SPLIT");
+      split = e ? atoi(e) : 2;
+      if (split != 1 && split != 4) split = 2;
+    }
+    int rg = split;
+    while (rg > 1 && a[0].H % (4 * rg) != 0) rg >>= 1;
+    if (tag && persist_tag_enabled() && split_bf16_enabled() && a[0].H % 16 == 0 && a[0].H / 16 <= 32 &&
+        a[0].H / (4 * rg) <= P_MAXB)
+      return launch_rnn_backward_persist_tag(a, ns, s, rg);
+  }
   unsigned* sync = nullptr;
   int* status = nullptr;
   CVAE_TRY(persist_sync(s, &sync, &status));
