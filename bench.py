@@ -44,7 +44,9 @@ SPLIT_BF16 = True
 KERNELS = {0: ('gemm_tiled_kernel', 'mfma'), 1: ('skinny_kernel', 'mfma'), 2: ('cell_fwd_kernel', 'hbm'),
            3: ('cell_bwd_kernel', 'hbm'), 4: ('ce_core_kernel', 'mfma'), 5: ('gemm_wide_kernel', 'mfma'),
            6: ('rnn_fwd_persist_kernel', 'mfma'), 7: ('rnn_bwd_persist_kernel', 'mfma'),
-           8: ('rnn_large_step_kernel', 'mfma'), 9: ('gemm_nt_kernel', 'mfma')}
+           8: ('rnn_large_step_kernel', 'mfma'), 9: ('gemm_nt_kernel', 'mfma'), 10: ('clip_adam_kernel', 'hbm'),
+           11: ('ce_grad_from_logits_kernel', 'hbm'), 12: ('iw_reduce_kernel', 'hbm')}
+HBM_KERNELS = ('clip_adam_kernel', 'ce_grad_from_logits_kernel', 'iw_reduce_kernel')
 
 
 def parse():
@@ -59,6 +61,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-iw', action='store_true')
     ap.add_argument('--no-ptb', action='store_true', help='skip the PTB-shape LSTM sub-record')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32-input-MFMA sub-record')
     ap.add_argument('--iw-shard', default='sentences', choices=['sentences', 'samples'],
                     help='N > 1: shard evaluation batches over ranks (weak scaling, default) or the K samples of '
                          'every sentence (same batches on every rank, all-gather of the cross-entropy rows)')
@@ -119,7 +122,7 @@ def pmc_traffic(kernel):
 
 def roofline_of(prof, region):
     """The kernel with the largest total time in the profiled pass."""
-    name, rec = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    name, rec = max(((k, v) for k, v in prof.items() if k not in HBM_KERNELS), key=lambda kv: kv[1]['ms'])
     if rec['launches'] == 0 or rec['ms'] == 0:
         return None
     per_s = rec['work'] / (rec['ms'] * 1e-3)
@@ -141,6 +144,33 @@ def roofline_of(prof, region):
         out['note'] = ('achieved = algorithmic fp32 FLOP/s (2*M*N*K per launch); peak = dense bf16 MFMA peak / %d passes; '
                        'against the fp32-input MFMA peak of %.1f TFLOP/s the same figure is %.2fx'
                        % (SPLIT_BF16_KERNELS[name], PEAK_F32_MFMA_TFLOPS, ach / PEAK_F32_MFMA_TFLOPS))
+    return out
+
+
+def pmc_hbm_bytes(kernel):
+    """HBM-side bytes per launch of a bandwidth kernel from the committed PMC passes (profiles/r03_pmc_hbm_summary.json,
+    FETCH_SIZE doubled as the guide prescribes for gfx950), or None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_summary.json')))[kernel]
+        return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def roofline_hbm(profs):
+    """Achieved GB/s of the bandwidth-shaped kernels (algorithmic bytes = every input and output once, SURVEY 8d,
+    divided by the HIP-event duration of their launches) against the 8 TB/s HBM peak."""
+    out = {}
+    for prof in profs:
+        for name in HBM_KERNELS:
+            rec = (prof or {}).get(name)
+            if not rec or rec['launches'] == 0 or rec['ms'] == 0 or name in out:
+                continue
+            gbs = rec['work'] / (rec['ms'] * 1e-3) / 1e9
+            out[name] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                             frac=round(gbs / PEAK_HBM_GBS, 4), launches=rec['launches'],
+                             avg_launch_ms=round(rec['ms'] / rec['launches'], 5),
+                             bytes_per_launch=round(rec['work'] / rec['launches']), traffic=pmc_hbm_bytes(name))
     return out
 
 
@@ -301,6 +331,10 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
     from cvae_amd import _lib, data, harness, settings
     _lib.init(local_rank)
+    gathered_devices = ['cuda:%d' % local_rank]
+    if world > 1:                                   # which device every rank drives (the `collective` record)
+        gathered_devices = [None] * world
+        dist.all_gather_object(gathered_devices, '%s/cuda:%d' % (os.uname().nodename, local_rank))
     global SPLIT_BF16
     SPLIT_BF16 = bool(_lib.query('cvae_split_bf16', 1))          # returns the previous (= configured) setting ...
     _lib.query('cvae_split_bf16', int(SPLIT_BF16))               # ... which stays in force
@@ -422,10 +456,28 @@ def main():
             roof_eval = roofline_of(prof_e, 'IW-NLL evaluation (%d batches)' % args.iw_batches)
             roof_all['iw_nll'] = table(prof_e)
             # the kernel with the largest total time over the whole job (both legs scaled to what the job ran)
-            k_train = max(v['ms'] for v in prof_t.values()) / n_leg * (args.steps + args.warmup)
-            k_eval = max(v['ms'] for v in prof_e.values()) * (args.iw_batches + 1.0) / args.iw_batches
+            k_train = max(v['ms'] for k, v in prof_t.items() if k not in HBM_KERNELS) / n_leg * (args.steps + args.warmup)
+            k_eval = max(v['ms'] for k, v in prof_e.items() if k not in HBM_KERNELS) * (args.iw_batches + 1.0) / args.iw_batches
             roof = roof_eval if (roof_eval and k_eval >= k_train) else roof_train
+    roof_hbm = roofline_hbm([prof_t, prof_e]) if rank == 0 else None
     barrier_sync(world)
+
+    # ---- the same step and evaluation on the fp32-input MFMA kernels (cvae_split_bf16(0)): what the split-bf16
+    # products buy, beside `value` in the same line
+    fp32 = None
+    if SPLIT_BF16 and not args.no_fp32:
+        _lib.query('cvae_split_bf16', 0)
+        try:
+            fdt, ftoks = run_training(tr, batches, tokens, args, world, dev, rank)
+            fp32 = dict(arithmetic='fp32-input MFMA everywhere (cvae_split_bf16(0))', value=round(ftoks, 1), unit='tokens/s',
+                        ms_per_step=round(fdt / max(args.steps, 1) * 1e3, 3))
+            if not args.no_iw:
+                _, fiw = run_iw(tr, data, harness, shape, B, args.iw_batches, args.iw_samples,
+                                args.iw_shard == 'samples' and world > 1, world, dev, rank)
+                fp32['iw_nll'] = fiw
+        finally:
+            _lib.query('cvae_split_bf16', 1)
+        log(rank, 'fp32-input kernels: %.3f ms/step' % fp32['ms_per_step'])
 
     if rank == 0:
         out = {
@@ -433,7 +485,7 @@ def main():
             'value': round(train_tok_s, 1), 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / max(args.steps, 1) * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32 (split-bf16x3/x6 products)' if SPLIT_BF16 else 'f32',
             'dtype_note': ('fp32 storage, accumulation and results; the hidden x vocab product and the many-row gate product of '
                            'IW evaluation run as error-compensated split-bf16 (3 bf16 MFMA passes per fp32 product; error vs fp64 '
                            'equal to the fp32-input MFMA kernels: tests/test_gpu_kernels.py::test_projce_bf16x3_error), the '
@@ -444,9 +496,20 @@ def main():
                                    'lengths lognormal(%.1f,%.2f) cap %d, rows in corpus (shuffled) order; train step + IW-NLL K=%d'
                                    % (args.workload, args.cell, shape['V'], shape['E'], shape['H'], shape['Z'], B,
                                       shape['mu'], shape['sigma'], shape['cap'], args.iw_samples),
+                       'headline': ('`value` is BASELINE.json configs[1] (the 1-GPU configuration: Yelp shape, train step; '
+                                    'IW-NLL K=500 in `iw_nll`); `ptb_lstm` is the shape the metric string names '
+                                    '(configs[0], the reference\'s CPU-runnable case) measured the same way'
+                                    if args.workload == 'yelp' else 'workload selected with --workload'),
                        'parallelism': 'dp%d' % world},
-            'iw_nll': iw, 'ptb_lstm': ptb, 'train_bucketed': bucketed, 'roofline': roof, 'roofline_train': roof_train, 'kernels': roof_all,
+            'iw_nll': iw, 'ptb_lstm': ptb, 'train_bucketed': bucketed, 'fp32_mfma': fp32, 'roofline': roof,
+            'roofline_train': roof_train, 'roofline_hbm': roof_hbm, 'kernels': roof_all,
         }
+        if world > 1:
+            out['collective'] = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
+                                     devices=sorted(set(gathered_devices)),
+                                     gradient_all_reduce='flat arena, buckets of %d MB issued from autograd hooks'
+                                                         % (settings.dp_bucket_bytes >> 20),
+                                     buckets_issued_early_last_step=tr.opt.issued_early)
         if world == 1 and not args.no_cpu_baseline:
             log(rank, 'CPU baseline (oracle)')
             out['cpu_baseline'] = cpu_baseline(args, shape)

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "misc.hpp"
 
+namespace cvae { int g_timing_build = 0; }
 namespace cvae {
 
 static thread_local char g_err[512] = "";
@@ -109,20 +110,46 @@ int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero, boo
   return 0;
 }
 
-static int* g_status_host = nullptr;     // host address of the mapped word
-static int* g_status_dev = nullptr;      // the same word as the device sees it
+// Releases the library-owned buffers of one stream of the current device (all streams of all devices: every = true).
+// The stream (device) is synchronised first: no kernel may still be using them.
+static int lib_scratch_release(hipStream_t s, bool every) {
+  int dev = 0;
+  CVAE_TRY(check_hip(hipGetDevice(&dev), "release: hipGetDevice"));
+  if (every) CVAE_TRY(check_hip(hipDeviceSynchronize(), "release: hipDeviceSynchronize"));
+  else CVAE_TRY(check_hip(hipStreamSynchronize(s), "release: hipStreamSynchronize"));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+    const bool hit = every ? std::get<1>(it->first) == dev : (std::get<1>(it->first) == dev && std::get<2>(it->first) == s);
+    if (hit) {
+      if (it->second.p) CVAE_TRY(check_hip(hipFree(it->second.p), "release: hipFree"));
+      it = g_scratch.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  return 0;
+}
+
+constexpr int kMaxDevices = 64;
+static int* g_status_host = nullptr;     // host address of the mapped word (portable: every device can map it)
+static int* g_status_dev[kMaxDevices] = {};      // the same word as each device sees it
 int persist_status_word(int** dev_ptr) {
+  int dev = 0;
+  CVAE_TRY(check_hip(hipGetDevice(&dev), "persist status: hipGetDevice"));
+  CVAE_REQUIRE(dev >= 0 && dev < kMaxDevices, "persist status: device %d", dev);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!g_status_host) {
     void* h = nullptr;
-    CVAE_TRY(check_hip(hipHostMalloc(&h, 64, hipHostMallocMapped), "persist status: hipHostMalloc"));
+    CVAE_TRY(check_hip(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable), "persist status: hipHostMalloc"));
     memset(h, 0, 64);
-    void* d = nullptr;
-    CVAE_TRY(check_hip(hipHostGetDevicePointer(&d, h, 0), "persist status: hipHostGetDevicePointer"));
     g_status_host = static_cast<int*>(h);
-    g_status_dev = static_cast<int*>(d);
   }
-  if (dev_ptr) *dev_ptr = g_status_dev;
+  if (!g_status_dev[dev]) {              // the device pointer belongs to the device that is current
+    void* d = nullptr;
+    CVAE_TRY(check_hip(hipHostGetDevicePointer(&d, g_status_host, 0), "persist status: hipHostGetDevicePointer"));
+    g_status_dev[dev] = static_cast<int*>(d);
+  }
+  if (dev_ptr) *dev_ptr = g_status_dev[dev];
   return 0;
 }
 // host-side views for rnn_persist.hip
@@ -199,7 +226,7 @@ using namespace cvae;
 
 extern "C" {
 
-int cvae_version(void) { return 100; }
+int cvae_version(void) { return cvae::g_timing_build ? -100 : 100; }
 const char* cvae_last_error(void) { return g_err; }
 
 int cvae_init(int device) {
@@ -1171,6 +1198,8 @@ int cvae_clip_adam_late(float* params, float* grads, float* m, float* v, int64_t
   return launch_clip_adam(params, grads, m, v, n, alias_off, alias_n, alias_mult, max_norm, lr, beta1, beta2, eps,
                           step_other, step_alias, late_off, late_n, step_late, sumsq, norm_out, S(stream));
 }
+int cvae_release_stream(void* stream) { return lib_scratch_release(S(stream), false); }
+int cvae_shutdown(void) { return lib_scratch_release(nullptr, true); }
 int cvae_persist_status(void) { return persist_status_and_clear(); }
 int cvae_persist_status_peek(void) { return persist_status_peek(); }
 int cvae_persist_status_set(int value) {

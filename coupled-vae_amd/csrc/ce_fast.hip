@@ -827,6 +827,7 @@ int launch_ce_fast_backward(const float* X, const float* W, const float* bias, c
     if (logits) {
       a.P = P;
       const int nblk = (int)(rc < 8192 ? rc : 8192);
+      ProfScope prof(PK_CE_GRAD, s, 8.0 * lrc * V);        // algorithmic bytes: the live rows' logits in, their gradient out
       hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, a);
       CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
     } else {
@@ -931,6 +932,7 @@ int launch_ce_fast_backward_n(int nd, const float* const* X, const float* const*
   }
   auto to_gradient = [&](int d) -> int {
     const int nblk = (int)(N < 8192 ? N : 8192);
+    ProfScope prof(PK_CE_GRAD, s, 8.0 * live * V);         // algorithmic bytes: the live rows' logits in, their gradient out
     hipLaunchKernelGGL(ce_grad_from_logits_kernel, dim3(nblk), dim3(256), 0, s, ga[d]);
     CVAE_LAUNCH_CHECK("ce_grad_from_logits_kernel");
     return 0;

@@ -4,6 +4,24 @@
 #include <stdint.h>
 #include <stdio.h>
 
+// Timing-only diagnostic switches (CE_EXP_*, GW_EXP_*, RB_EXP_*: scripts/build_variant.sh) remove work from a kernel to
+// see what it costs; a library built with any of them computes garbage.  They are accepted only together with
+// -DCVAE_TIMING_BUILD, and every object compiled that way flips the sign of cvae_version(), so that the Python
+// binding (and tests/test_abi_and_host.py) refuse such a library unless CVAE_ALLOW_TIMING_BUILD=1.
+#if !defined(CVAE_TIMING_BUILD) && \
+    (defined(CE_EXP_NOLOAD) || defined(CE_EXP_NOLDS) || defined(CE_EXP_NOEPI) || \
+     (defined(GW_EXP_NOSPLIT) && GW_EXP_NOSPLIT) || (defined(GW_EXP_NOMFMA) && GW_EXP_NOMFMA) || \
+     (defined(GW_EXP_NOLOAD) && GW_EXP_NOLOAD) || (defined(GW_EXP_NOLDS) && GW_EXP_NOLDS) || \
+     (defined(RB_EXP_NOSPLIT) && RB_EXP_NOSPLIT) || (defined(RB_EXP_NOEPI) && RB_EXP_NOEPI) || \
+     (defined(RB_EXP_NOMFMA) && RB_EXP_NOMFMA))
+#error "*_EXP_* timing switches need -DCVAE_TIMING_BUILD (the library then reports a negative cvae_version())"
+#endif
+namespace cvae {
+extern int g_timing_build;              // api.hip; 1 once any object of the library was compiled with CVAE_TIMING_BUILD
+#ifdef CVAE_TIMING_BUILD
+namespace { struct TimingBuildMark { TimingBuildMark() { g_timing_build = 1; } } g_timing_build_mark; }
+#endif
+}
 namespace cvae {
 
 // ---- error plumbing: every extern "C" entry returns 0 or a negative code and leaves a
@@ -34,7 +52,8 @@ int check_hip(hipError_t e, const char* what);
 // ---- opt-in per-kernel timing (bench.py's roofline leg): HIP events recorded on the launch
 // stream around the kernels named below.  Off by default: no events, no overhead.
 enum ProfKernel { PK_GEMM_TILED = 0, PK_SKINNY = 1, PK_CELL_FWD = 2, PK_CELL_BWD = 3, PK_CE_FWD = 4, PK_GEMM_WIDE = 5,
-                  PK_RNN_PERSIST = 6, PK_RNN_PERSIST_BWD = 7, PK_RNN_LARGE = 8, PK_GEMM_NT = 9, PK_COUNT = 10 };
+                  PK_RNN_PERSIST = 6, PK_RNN_PERSIST_BWD = 7, PK_RNN_LARGE = 8, PK_GEMM_NT = 9,
+                  PK_CLIP_ADAM = 10, PK_CE_GRAD = 11, PK_IW_REDUCE = 12, PK_COUNT = 13 };   // 10-12: HBM-bound, work = bytes
 struct ProfScope {
   int slot;
   hipStream_t s;

@@ -126,11 +126,14 @@ __global__ void embed_scatter_kernel(int T, int B, int E, int W, int slot0, cons
 
 // Deterministic form: the same sums through 64-bit fixed point (2^-36 units; integer adds commute, so the order in
 // which the atomics land does not matter), then demb += fix * 2^-36 in one pass.  Resolution 1.5e-11, range +-1.3e8
-// per element; entries outside +-1e6 (never seen in a gradient that passes the clip) are clamped.
+// per element.  An addend that is not finite or lies outside +-1e6 (a diverged step) does not go through fixed
+// point: it is added to demb as a float, so a NaN / Inf / huge gradient stays visible in demb and in the clip norm
+// exactly as in the default path and in the reference (only such a step loses bit-reproducibility).
 constexpr double EMB_FIX_SCALE = 68719476736.0;   // 2^36
 __global__ void embed_scatter_fix_kernel(int T, int B, int E, int W, int slot0, const int64_t* __restrict__ ids,
                                          const float* __restrict__ dX, const float* __restrict__ mask,
-                                         const int64_t* __restrict__ mask_rows, unsigned long long* __restrict__ fix) {
+                                         const int64_t* __restrict__ mask_rows, unsigned long long* __restrict__ fix,
+                                         float* __restrict__ demb) {
   IDX1D((long)T * B * E);
   const int e = (int)(idx % E);
   const int b = (int)((idx / E) % B);
@@ -141,9 +144,13 @@ __global__ void embed_scatter_fix_kernel(int T, int B, int E, int W, int slot0, 
     v *= mask[((long)t * B + mr) * W + e];
   }
   if (v != 0.f) {
-    const double c = fmin(fmax((double)v, -1.0e6), 1.0e6);
-    const long long q = __double2ll_rn(c * EMB_FIX_SCALE);
-    atomicAdd(fix + ids[(long)b * T + t] * E + e, (unsigned long long)q);       // two's complement: wraps like a signed add
+    const long o = ids[(long)b * T + t] * E + e;
+    if (!(fabsf(v) <= 1.0e6f)) {                      // NaN, Inf or out of the fixed-point range: propagate as it is
+      atomicAdd(demb + o, v);
+    } else {
+      const long long q = __double2ll_rn((double)v * EMB_FIX_SCALE);
+      atomicAdd(fix + o, (unsigned long long)q);      // two's complement: wraps like a signed add
+    }
   }
 }
 __global__ void embed_fix_apply_kernel(long n, unsigned long long* __restrict__ fix, float* __restrict__ demb) {
@@ -164,7 +171,7 @@ int launch_embed_scatter(int T, int B, int E, int W, int slot0, const int64_t* i
     CVAE_TRY(lib_scratch(LS_EMB_FIX, s, (size_t)V * E * sizeof(unsigned long long), &buf, 1, &fresh));
     unsigned long long* fix = static_cast<unsigned long long*>(buf);
     hipLaunchKernelGGL(embed_scatter_fix_kernel, GRID1D((long)T * B * E), 0, s, T, B, E, W, slot0, ids, dX, mask,
-                       mask_rows, fix);
+                       mask_rows, fix, demb);
     CVAE_LAUNCH_CHECK("embed_scatter_fix_kernel");
     hipLaunchKernelGGL(embed_fix_apply_kernel, GRID1D((long)V * E), 0, s, (long)V * E, fix, demb);
     CVAE_LAUNCH_CHECK("embed_fix_apply_kernel");
@@ -1171,6 +1178,7 @@ int launch_iw_reduce(const float* z, const float* xent, const float* mu, const f
   CVAE_REQUIRE(K <= 12000, "iw_reduce: K=%d exceeds the LDS-resident limit (12000)", K);
   CVAE_REQUIRE((mu_p == nullptr) == (sigma_p == nullptr), "iw_reduce: prior needs both mu_p and sigma_p");
   if (B == 0) return 0;
+  ProfScope prof(PK_IW_REDUCE, s, 4.0 * ((double)K * B * Z + (double)K * B + 2.0 * B * Z * (mu_p ? 2 : 1) + 3.0 * B));
   hipLaunchKernelGGL(iw_reduce_kernel, dim3(B), dim3(256), (((K + 1) & ~1) + 24) * sizeof(float), s, K, B, Z, z, xent, mu, sigma,
                      mu_p, sigma_p, nll, kl, xent_mean);
   CVAE_LAUNCH_CHECK("iw_reduce_kernel");
@@ -1408,6 +1416,7 @@ int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_
     sa.step_size[r] = (float)((double)lr / (1.0 - pow((double)b1, (double)(step_alias + 1 + r))));
     sa.bc2_sqrt[r] = (float)sqrt(1.0 - pow((double)b2, (double)(step_alias + 1 + r)));
   }
+  ProfScope prof(PK_CLIP_ADAM, s, 32.0 * n);              // algorithmic bytes: grads, params, m, v each read and written once
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, n, alias_off, alias_off + alias_n, mult,
                      max_norm, b1, b2, eps, so, sa, late_off, late_off + late_n, late_skip ? 1 : 0,
                      sl, parts, sgrid, sumsq, p, g, m, v, norm_out, status_copy);

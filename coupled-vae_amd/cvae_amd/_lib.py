@@ -25,6 +25,8 @@ P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argtypes, exactly as declared in include/cvae_hip.h (restype int unless listed)
 SIGNATURES = {
     'cvae_version': [],
+    'cvae_release_stream': [P],
+    'cvae_shutdown': [],
     'cvae_init': [I],
     'cvae_pack_batch': [P, P, I, I, I, L, L, L, P, P, P, P, P],
     'cvae_pack_batch_indexed': [P, P, P, I, I, I, L, L, L, P, P, P, P, P],
@@ -99,6 +101,9 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = L if _name in _RESTYPE_LONG else I
 lib.cvae_last_error.argtypes = []
 lib.cvae_last_error.restype = ctypes.c_char_p
+if lib.cvae_version() < 0 and os.environ.get('CVAE_ALLOW_TIMING_BUILD') != '1':
+    raise ImportError('%s is a timing-only diagnostic build (an *_EXP_* switch removed work from a kernel: its '
+                      'results are wrong); set CVAE_ALLOW_TIMING_BUILD=1 to load it for timing' % LIB_PATH)
 
 
 class CvaeHipError(RuntimeError):

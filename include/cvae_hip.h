@@ -8,12 +8,16 @@
  * Conventions
  *  - every pointer is a DEVICE pointer unless named host_*; float = fp32, ids = int64.
  *  - row-major, contiguous tensors; sequences are time-major inside the library: (T, B, .).
- *  - `stream` is a hipStream_t (NULL = default stream); all work is enqueued, nothing syncs.
+ *  - `stream` is a hipStream_t (NULL = default stream); all work is enqueued and, in the steady state, nothing
+ *    synchronises or allocates.  The exception is warm-up: the FIRST call on a (device, stream) that needs one of
+ *    the library-owned buffers listed below, or a call with a larger shape than any before, hipMallocs it
+ *    (hipMemset; on regrowth hipFree, which synchronises the device).  cvae_release_stream / cvae_shutdown free them.
  *  - return 0 on success, negative on error; cvae_last_error() returns the message
  *    (thread-local).  Shape / pointer preconditions are checked on the host before launch.
  *  - workspaces are passed in by the caller.  Exceptions owned by the library, one set per (device, stream),
  *    allocated at their first use and regrown only when a larger shape arrives (warm-up; steady-state calls
- *    allocate nothing): the whole-sequence recurrent kernels' flag words and partial-gradient exchange, the
+ *    allocate nothing): the whole-sequence recurrent kernels' sync words and partial-gradient exchange (armed with
+ *    a sentinel word by a fill launch before every backward recurrence), the
  *    split-K products' partial-sum slabs, the live-row index lists of the backward passes, the weight images of the
  *    weight-streaming recurrent step kernels, the clip norm's per-block partial sums and (cvae_deterministic only)
  *    the fixed-point buffer of the embedding-gradient scatter.
@@ -27,6 +31,8 @@
 extern "C" {
 #endif
 
+/* 100 for a product build; negative for a timing-only diagnostic build (an *_EXP_* switch removed work from a kernel:
+ * results are wrong, csrc/common.hpp) -- bindings refuse those. */
 int cvae_version(void);
 const char* cvae_last_error(void);
 /* Checks that `device` is a gfx950 part and makes it current. */
@@ -370,6 +376,16 @@ int64_t cvae_stream_rnn_min_bytes(int64_t bytes);
  * kernels whose row count lives on the device (4, 5) count the live rows. */
 int cvae_profile_enable(int on);
 int cvae_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_work);
+
+/* Library-owned device buffers (split-K slabs, the recurrent kernels' exchange and sync words, live-row lists,
+ * weight images, the fixed-point embedding accumulator) are kept per (device, stream), allocated at the first call
+ * that needs them and regrown when a larger shape arrives -- those calls hipMalloc / hipMemset (and hipFree on
+ * regrowth, which synchronises the device): warm every shape up once before timing or capturing.  A process that
+ * creates and destroys streams calls cvae_release_stream(stream) before destroying one (synchronises that stream,
+ * frees its buffers on the current device; a later stream that reuses the handle starts clean); cvae_shutdown()
+ * does the same for every stream of the current device.  No counterpart in the reference. */
+int cvae_release_stream(void* stream);
+int cvae_shutdown(void);
 
 /* small helpers used by the host mirror */
 /* Synchronises the device and returns (then clears) the timeout word of the whole-sequence

@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/../coupled-vae_amd/csrc"
 make -s
 name=$1; file=$2; flags=$3
+case "$flags" in *_EXP_*) flags="$flags -DCVAE_TIMING_BUILD";; esac      # results are wrong: cvae_version() < 0
 mkdir -p build/var ../lib/var
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c "$file" -o "build/var/${name}.o"
 objs=""

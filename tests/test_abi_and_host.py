@@ -136,3 +136,21 @@ def test_run_reference_launcher_puts_the_dropin_first(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1500:]
     assert r.stdout.split() == ['cvae_amd.modules', 'cvae_amd.modules', 'Coupled-VAE', "['x']", '__main__']
+
+
+def test_library_is_not_a_timing_build():
+    """A library compiled with any *_EXP_* timing switch (scripts/build_variant.sh; kernels with work removed)
+    reports a negative version; the product build must not be one."""
+    from cvae_amd import _lib
+    assert _lib.query('cvae_version') >= 100
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    guard = open(os.path.join(root, 'coupled-vae_amd', 'csrc', 'common.hpp')).read()
+    for hook in ('CE_EXP_NOLOAD', 'CE_EXP_NOLDS', 'CE_EXP_NOEPI', 'GW_EXP_NOSPLIT', 'GW_EXP_NOMFMA', 'GW_EXP_NOLOAD',
+                 'GW_EXP_NOLDS', 'RB_EXP_NOSPLIT', 'RB_EXP_NOEPI', 'RB_EXP_NOMFMA'):
+        assert hook in guard, 'timing switch %s is not covered by the CVAE_TIMING_BUILD guard' % hook
+    # every *_EXP_* name used anywhere in the kernels is one of the guarded ones
+    import glob, re
+    used = set()
+    for f in glob.glob(os.path.join(root, 'coupled-vae_amd', 'csrc', '*.hip')):
+        used |= set(re.findall(r'\b[A-Z]{2}_EXP_[A-Z]+\b', open(f).read()))
+    assert used and all(u in guard for u in used), sorted(used)

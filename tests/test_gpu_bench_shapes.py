@@ -225,3 +225,54 @@ def test_deterministic_mode_is_bit_reproducible(dev):
         _lib.query('cvae_deterministic', prev)
     assert all(abs(x[0] - y[0]) < 1e-5 * abs(y[0]) for x, y in zip(a, d))
     assert float((pa - pd).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_propagates_non_finite_gradients(dev):
+    """A diverged step must stay visible: with a NaN weight in the encoder the embedding gradient and the clip norm are
+    NaN in the deterministic mode exactly as in the default one (the fixed-point scatter takes finite addends within
+    its range only; anything else is added as a float)."""
+    from cvae_amd import data, harness, _lib
+    hp = harness.HParams(model='vae-couple', cell='lstm', V=300, E=32, H=128, Z=8, batch_size=16, dropout=0.0)
+    c = data.Corpus(data.synthetic_sentences(16, 300, 2.3, 0.4, 20, seed=3))
+    prev = _lib.query('cvae_deterministic', 0)
+    try:
+        for det in (0, 1):
+            _lib.query('cvae_deterministic', det)
+            tr = harness.Trainer(hp, dev, seed=1)
+            tr.model.Encoder.LSTM.weight_ih_l0.data[0, 0] = float('nan')
+            tr.forward_backward(harness.text_batch(c, range(16), dev))
+            emb_grad = tr.model.Encoder.Embedding.weight.grad
+            assert bool(torch.isnan(emb_grad).any()), det
+            tr.opt.step()
+            assert bool(torch.isnan(tr.opt.norm).all()), det
+    finally:
+        _lib.query('cvae_deterministic', prev)
+        _lib.query('cvae_persist_status')
+
+
+@pytest.mark.gpu
+def test_release_stream_frees_the_library_buffers(dev):
+    """cvae_release_stream: the (device, stream) buffers go back to the driver and the next call on that stream
+    allocates fresh ones and computes the same values."""
+    from cvae_amd import _lib, ops
+    side = torch.cuda.Stream()
+    n = 1 << 20
+    g = torch.randn(n, device=dev)
+
+    def step():
+        p, m, v = torch.ones(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sumsq, norm = torch.zeros(2, device=dev), torch.zeros(1, device=dev)
+        with torch.cuda.stream(side):
+            ops.clip_adam(p, g.clone(), m, v, 0, 0, 1, 5.0, 1e-3, (0.9, 0.999), 1e-8, 0, 0, sumsq, norm)
+        side.synchronize()
+        return p, float(norm)
+
+    torch.cuda.synchronize()
+    side.wait_stream(torch.cuda.current_stream())
+    p1, n1 = step()
+    assert _lib.query('cvae_release_stream', side.cuda_stream) == 0
+    assert _lib.query('cvae_release_stream', side.cuda_stream) == 0          # nothing left: still fine
+    p2, n2 = step()
+    assert n1 == n2 and torch.equal(p1, p2)
+    assert _lib.query('cvae_release_stream', side.cuda_stream) == 0

@@ -28,9 +28,29 @@ def test_mi_static_matches_mi_on_consecutive_calls():
         out = torch.full((B,), float('nan'), device=dev)
         torch.cuda.synchronize()
         before = torch.cuda.memory_stats(dev)['allocation.all.allocated']
+        free_before = torch.cuda.mem_get_info(dev)[0]          # hipMemGetInfo: sees a hipMalloc / hipFree inside the library
         got = ops.mi_static(z, mu, sg, out=out)
+        torch.cuda.synchronize()
         assert torch.cuda.memory_stats(dev)['allocation.all.allocated'] == before      # torch allocated nothing either
+        assert torch.cuda.mem_get_info(dev)[0] == free_before                          # ... and neither did the library
         assert got.data_ptr() == out.data_ptr() and torch.equal(got, want), (K, B)
+    # the call is legal under stream capture, where any allocation or synchronisation fails: one captured call,
+    # replayed on new inputs written into the captured buffers
+    z, mu, sg = _case(100, 513, 32, 7, dev)
+    out = torch.empty((513,), device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.mi_static(z, mu, sg, out=out)                       # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.mi_static(z, mu, sg, out=out)
+    z2, mu2, sg2 = _case(100, 513, 32, 8, dev)
+    z.copy_(z2); mu.copy_(mu2); sg.copy_(sg2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ops.mi(z2, mu2, sg2))
     z, mu, sg = _case(257, 512, 8, 5, dev)                                             # one sample past the limit
     with pytest.raises(_lib.CvaeHipError, match='static scratch limit'):
         ops.mi_static(z, mu, sg)
