@@ -102,17 +102,18 @@ def profile_read(lib):
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_hbm_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from
-    inside this process, so the figure is the recorded one for the same workload, or None."""
+    (profiles/r03_pmc_hbm_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench,
+    scripts/collect_profiles_r03.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters
+    cannot be read from inside this process, so the figure is the recorded one for the same workload, or None."""
     if kernel != 'ce_core_kernel':
         return None
-    for name in ('r02_pmc_hbm_summary.json', 'r01_pmc_hbm_summary.json'):
+    for name, split in (('r03_pmc_hbm_summary.json', True), ('r02_pmc_hbm_summary.json', None), ('r01_pmc_hbm_summary.json', None)):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             rec = json.load(open(path))['ce_core_forward_eval_launch']
             # the record must be of the variant this run launches (split-bf16 or fp32-input)
-            if ('ce_core_bf3_kernel' in rec.get('kernel', '')) != SPLIT_BF16:
+            is_split = split if split is not None else ('ce_core_bf3_kernel' in rec.get('kernel', ''))
+            if is_split != SPLIT_BF16:
                 continue
             return round(rec['fetch_bytes_corrected_avg'] + rec['write_bytes_avg'])
         except (OSError, KeyError, ValueError, TypeError):
