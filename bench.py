@@ -282,6 +282,7 @@ def run_training(tr, batches, tokens, args, world, dev, rank):
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         tr.train_step(batches[i])
+    tr.dp_flush()                      # data-parallel: a time-out in the last steps is handled before the clock stops
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     if _lib.query('cvae_persist_status') != 0:
@@ -510,7 +511,9 @@ def main():
                                      devices=sorted(set(gathered_devices)),
                                      gradient_all_reduce='flat arena, buckets of %d MB issued from autograd hooks'
                                                          % (settings.dp_bucket_bytes >> 20),
-                                     buckets_issued_early_last_step=tr.opt.issued_early)
+                                     buckets_issued_early_last_step=tr.opt.issued_early,
+                                     persist_headroom_cus=settings.dp_persist_headroom,
+                                     iterations_rerun_on_per_step_kernels=list(tr.fallbacks))
         if world == 1 and not args.no_cpu_baseline:
             log(rank, 'CPU baseline (oracle)')
             out['cpu_baseline'] = cpu_baseline(args, shape)

@@ -1200,6 +1200,10 @@ int cvae_clip_adam_late(float* params, float* grads, float* m, float* v, int64_t
 }
 int cvae_release_stream(void* stream) { return lib_scratch_release(S(stream), false); }
 int cvae_shutdown(void) { return lib_scratch_release(nullptr, true); }
+int cvae_persist_status_export(float* dst, void* stream) { return launch_status_export(dst, S(stream)); }
+int cvae_persist_status_import(const float* src, void* stream) { return launch_status_import(src, S(stream)); }
+int cvae_persistent_rnn(int on) { return persist_rnn_set(on); }
+int cvae_persist_headroom(int cus) { return persist_headroom_set(cus); }
 int cvae_persist_status(void) { return persist_status_and_clear(); }
 int cvae_persist_status_peek(void) { return persist_status_peek(); }
 int cvae_persist_status_set(int value) {

@@ -294,5 +294,7 @@ struct ZeroBatch;
 int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb = nullptr);
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s);
 int persist_status_and_clear();
+int persist_rnn_set(int on);           // runtime form of CVAE_PERSISTENT_RNN; returns the previous setting
+int persist_headroom_set(int cus);     // CUs left free by the whole-sequence kernels (cus < 0: query); returns the previous value
 
 }  // namespace cvae

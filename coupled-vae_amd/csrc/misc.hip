@@ -1286,6 +1286,33 @@ int launch_mi_static(const float* z, const float* mu, const float* sigma, int K,
   return launch_mi(z, mu, sigma, K, B, Z, ptr, ptr + (long)K * B, mi, s);
 }
 
+// ------------------------------------------------------------------ status word <-> device float
+// A data-parallel job folds the recurrent kernels' time-out word into its gradient all-reduce: export writes it as a
+// float into a spare arena slot before the collective, import raises the local word when the reduced slot is
+// non-zero (some rank timed out), so that cvae_clip_adam skips the step on EVERY rank and the replicas stay identical.
+__global__ void status_export_kernel(const int* __restrict__ status, float* __restrict__ dst) {
+  *dst = (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) ? 1.f : 0.f;
+}
+__global__ void status_import_kernel(const float* __restrict__ src, int* __restrict__ status) {
+  if (*src != 0.f) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int launch_status_export(float* dst, hipStream_t s) {
+  CVAE_REQUIRE(dst, "persist_status_export: null destination");
+  int* status = nullptr;
+  CVAE_TRY(persist_status_word(&status));
+  hipLaunchKernelGGL(status_export_kernel, dim3(1), dim3(1), 0, s, status, dst);
+  CVAE_LAUNCH_CHECK("status_export_kernel");
+  return 0;
+}
+int launch_status_import(const float* src, hipStream_t s) {
+  CVAE_REQUIRE(src, "persist_status_import: null source");
+  int* status = nullptr;
+  CVAE_TRY(persist_status_word(&status));
+  hipLaunchKernelGGL(status_import_kernel, dim3(1), dim3(1), 0, s, src, status);
+  CVAE_LAUNCH_CHECK("status_import_kernel");
+  return 0;
+}
+
 // ------------------------------------------------------------------ clip + Adam (a12)
 // out[b] = block b's sum over all grads^2, out[SUMSQ_MAX_BLOCKS + b] = its sum over the alias segment.  No float
 // atomics: the clip norm is the same bits on every run (and on every rank of a data-parallel job).

@@ -81,6 +81,8 @@ int mi_static_init(int device);
 long mi_static_max_rows();
 int launch_mi_static(const float* z, const float* mu, const float* sigma, int K, int B, int Z, float* mi,
                      hipStream_t s);
+int launch_status_export(float* dst, hipStream_t s);
+int launch_status_import(const float* src, hipStream_t s);
 int launch_clip_adam(float* p, float* g, float* m, float* v, long n, long alias_off, long alias_n, int mult,
                      float max_norm, float lr, float b1, float b2, float eps, long step_other, long step_alias,
                      long late_off, long late_n, long step_late, float* sumsq, float* norm_out, hipStream_t s);

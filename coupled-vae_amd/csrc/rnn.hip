@@ -182,6 +182,13 @@ int launch_rnn_forward_multi(const RnnFwd* a, int ns, hipStream_t s) {
   if (aligned && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, ns))
     return launch_rnn_forward_persist(a, ns, s, &zb);      // its flag words join the same zero launch
   CVAE_TRY(zb.flush());
+  // the lock-stepped sequences together need more CUs than there are free ones (cvae_persist_headroom: a
+  // data-parallel job keeps some for RCCL's kernels), but half of them fit: two whole-sequence launches
+  if (aligned && ns > 1 && rnn_persist_supported(a[0].cell, a[0].T, a[0].R, a[0].H, (ns + 1) / 2)) {
+    const int h = (ns + 1) / 2;
+    CVAE_TRY(launch_rnn_forward_persist(a, h, s, nullptr));
+    return launch_rnn_forward_persist(a + h, ns - h, s, nullptr);
+  }
   if (aligned && stream_rnn_supported(a[0].R, a[0].H, a[0].cell == CELL_GRU ? 3 : 4)) return rnn_forward_stream(a, ns, s);
   SkinnyArgs k[SKINNY_MAX_BATCH];
   for (int i = 0; i < a[0].T; ++i) {
@@ -399,6 +406,11 @@ int launch_rnn_backward_multi(const RnnBwd* arr, int ns, hipStream_t s) {
     aligned = aligned && aligned16(arr[q].dgx) && (!arr[q].dgh || aligned16(arr[q].dgh)) && aligned16(arr[q].W_hh);
   if (aligned && rnn_persist_bwd_supported(arr[0].cell, arr[0].T, arr[0].R, arr[0].H, ns))
     return launch_rnn_backward_persist(arr, ns, s);
+  if (aligned && ns > 1 && rnn_persist_bwd_supported(arr[0].cell, arr[0].T, arr[0].R, arr[0].H, (ns + 1) / 2)) {
+    const int h = (ns + 1) / 2;                            // see launch_rnn_forward_multi
+    CVAE_TRY(launch_rnn_backward_persist(arr, h, s));
+    return launch_rnn_backward_persist(arr + h, ns - h, s);
+  }
   if (aligned && stream_rnn_supported(arr[0].R, arr[0].H, arr[0].cell == CELL_GRU ? 3 : 4)) return rnn_backward_stream(arr, ns, s);
   // ---- one launch per step (for all sequences): dh_{t-1} product with the previous step's cell backward fused in
   const int T = arr[0].T, H = arr[0].H, R = arr[0].R;

@@ -1219,13 +1219,26 @@ static int persist_sync(hipStream_t s, unsigned** out, int** status) {
 }
 static unsigned long long* persist_stamps() { return g_stamps_last; }
 
+static int g_persist_on = -1;        // -1: not set yet (env CVAE_PERSISTENT_RNN, default on); cvae_persistent_rnn() sets it
 static int persist_enabled() {
-  static int on = -1;
-  if (on < 0) {
+  if (g_persist_on < 0) {
     const char* e = getenv("CVAE_PERSISTENT_RNN");
-    on = (e && e[0] == '0') ? 0 : 1;
+    g_persist_on = (e && e[0] == '0') ? 0 : 1;
   }
-  return on;
+  return g_persist_on;
+}
+int persist_rnn_set(int on) {
+  const int prev = persist_enabled();
+  g_persist_on = on ? 1 : 0;
+  return prev;
+}
+// CUs the whole-sequence kernels leave free (a data-parallel job keeps RCCL's kernels beside them)
+static int g_persist_headroom = -1;
+int persist_headroom_set(int cus) {
+  if (g_persist_headroom < 0) { const char* e = getenv("CVAE_PERSIST_HEADROOM"); g_persist_headroom = e ? atoi(e) : 0; }
+  const int prev = g_persist_headroom;
+  if (cus >= 0) g_persist_headroom = cus;
+  return prev;
 }
 
 static int cu_count() {
@@ -1237,7 +1250,7 @@ static int cu_count() {
 bool rnn_persist_supported(int cell, int T, int R, int H, int ns) {
   if (!persist_enabled() || T < 1 || R < 1 || R > 32 || ns < 1 || ns > SKINNY_MAX_BATCH) return false;
   if (H % 128 != 0 || H > 512) return false;
-  return H / P_HU <= P_MAXB && (H / P_HU) * ns <= cu_count();
+  return H / P_HU <= P_MAXB && (H / P_HU) * ns <= cu_count() - persist_headroom_set(-1);
 }
 
 // CVAE_PERSIST_TAG=0: the flag + payload hand-off (two round trips per step) instead of the in-band one

@@ -26,6 +26,10 @@ P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     'cvae_version': [],
     'cvae_release_stream': [P],
+    'cvae_persistent_rnn': [I],
+    'cvae_persist_status_export': [P, P],
+    'cvae_persist_status_import': [P, P],
+    'cvae_persist_headroom': [I],
     'cvae_shutdown': [],
     'cvae_init': [I],
     'cvae_pack_batch': [P, P, I, I, I, L, L, L, P, P, P, P, P],

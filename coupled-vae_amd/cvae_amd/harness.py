@@ -6,6 +6,7 @@ reference does not have: data-parallel training and sharded evaluation over RCCL
 Reference: CV/Experiment.py:509-558,578-621,639-775,1323-1396,1453-1503;
            CC/Experiment.py:311-428,538-621.
 """
+import collections
 import math
 
 import numpy as np
@@ -94,7 +95,10 @@ class FlatAdam(object):
         n = sum(pad4(p.numel()) for p in uniq)
         dev = uniq[0].device
         self.params = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        # 4 spare floats behind the gradients: [n] carries the recurrent kernels' time-out word through the
+        # data-parallel all-reduce (export_status / Trainer.train_step); never read by the optimizer
+        self.grads = torch.zeros(n + 4, dtype=torch.float32, device=dev)
+        self.n = n
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.alias_n = emb.numel() if emb is not None else 0
@@ -142,7 +146,7 @@ class FlatAdam(object):
             lo = self.offsets[i]
             hi = lo + self.views[i].numel()
             if cur is None or (hi - cur['lo']) * 4 > bucket_bytes:
-                cur = {'lo': lo, 'hi': hi, 'members': [], 'arrived': 0, 'work': None, 'fired': False}
+                cur = {'lo': lo, 'hi': hi, 'members': [], 'arrived': 0, 'work': None, 'fired': False, 'early': False}
                 self.buckets.append(cur)
             cur['hi'] = hi
             cur['members'].append(i)
@@ -191,12 +195,18 @@ class FlatAdam(object):
             self.views[i].grad = self.gviews[i]
         bucket['work'] = dist_utils.allreduce_sum_async(self.grads[bucket['lo']:bucket['hi']])
         bucket['fired'] = True
+        bucket['early'] = True
         self.issued_early += 1
 
     def finish_allreduce(self, world):
         """After backward: gathers what the hooks did not, reduces every bucket not issued yet, waits for all of
-        them and turns the sums into means.  Un-armed (first step, or dp_bucket_bytes = 0): one all-reduce."""
+        them and turns the sums into means.  Un-armed (first step, or dp_bucket_bytes = 0): one all-reduce.
+        The spare slot behind the gradients carries this rank's time-out word (0 / 1) into the reduction of the
+        LAST arena range (the first bucket of the backward pass is the highest one, so the slot has its own tiny
+        collective when that bucket is already in flight); afterwards grads[n] > 0 on every rank iff a
+        whole-sequence kernel timed out on some rank, and the local word is raised accordingly."""
         self.hooks_live = False
+        _lib.call('cvae_persist_status_export', self.grads[self.n:].data_ptr(), _lib.stream())
         if self.buckets is None:
             self._had_grad = [p.grad is not None for p in self.views]
         # a parameter outside the set learnt on the first step that has a gradient now (a loss term that switched
@@ -212,6 +222,7 @@ class FlatAdam(object):
         self.gather_grads()
         if self.buckets is None:
             dist_utils.allreduce_mean_(self.grads)
+            _lib.call('cvae_persist_status_import', self.grads[self.n:].data_ptr(), _lib.stream())
             return
         try:
             for b in reversed(self.buckets):                 # the same order as _fire_ready
@@ -220,17 +231,23 @@ class FlatAdam(object):
             for b in self.buckets:
                 if b['work'] is not None:
                     b['work'].wait()
-            for i in extra:                                  # same parameters, same order on every rank
-                dist_utils.allreduce_sum_async(self.gviews[i].view(-1)).wait()
+            tail = [self.gviews[i].view(-1) for i in extra]  # same parameters, same order on every rank
+            if self.buckets[-1]['early']:                    # its range went out before the status slot was written
+                tail.append(self.grads[self.n:])
+            for t in tail:
+                w = dist_utils.allreduce_sum_async(t)
+                if w is not None:                            # None: already complete (gloo, staged through the host)
+                    w.wait()
         finally:
             self.reset_buckets()
         self.grads.mul_(1.0 / world)
+        _lib.call('cvae_persist_status_import', self.grads[self.n:].data_ptr(), _lib.stream())
 
     def reset_buckets(self):
         """Bucket state of the iteration is dropped (also after a backward pass that raised)."""
         self.hooks_live = False
         for b in self.buckets or []:
-            b['work'], b['fired'], b['arrived'] = None, False, 0
+            b['work'], b['fired'], b['arrived'], b['early'] = None, False, 0, False
 
     def zero_grad(self):
         """Gradients are produced outside the arena and gathered once after backward (gather_grads):
@@ -306,6 +323,13 @@ class Trainer(object):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self._armed = False
+        # data-parallel jobs: see train_step
+        self._pending = collections.deque()      # (event, pinned copy of the reduced status slot, batch) of the last steps
+        self._cooldown = 0                       # steps left on the per-timestep kernels after a time-out
+        self._persist_prev = 1
+        self.fallbacks = []                      # iterations whose batches were re-run on the per-timestep kernels
+        if self.world > 1:
+            _lib.query('cvae_persist_headroom', settings.dp_persist_headroom)
 
     # ---- one training iteration: CV/Experiment.py:646-775 / CC/Experiment.py:318-428
     def losses(self, batch):
@@ -417,11 +441,64 @@ class Trainer(object):
 
     def train_step(self, batch):
         """forward + backward (+ gradient all-reduce) + clip + Adam.  Returns the loss dict
-        (device scalars: nothing syncs here; read them back in one copy when logging)."""
+        (device scalars: nothing syncs here; read them back in one copy when logging).
+
+        One process: a timed-out whole-sequence kernel raises (check_kernels).  Data-parallel (world > 1): a busy
+        chip must not stop the job, and every rank has to take the same decision on the same iteration.  The
+        time-out word of every rank rides through the gradient all-reduce (FlatAdam.finish_allreduce), so a
+        time-out anywhere raises the word everywhere before the clip: cvae_clip_adam then skips that step -- and
+        every later one, until the word is cleared -- on all ranks alike, and the replicas stay bit-identical.
+        The host looks at the REDUCED value of step k (the same number on every rank) two steps later, when that
+        step has certainly completed (no stall of the host's run-ahead): if it is set, the device is drained, the
+        word cleared, the recurrences switched to the per-timestep kernels (cvae_persistent_rnn(0), no restart)
+        for settings.dp_fallback_steps steps, and the batches of the skipped steps are re-run in order."""
+        if self.world > 1:
+            self._dp_check(lag=2)
+            if self._cooldown > 0:
+                self._cooldown -= 1
+                if self._cooldown == 0:
+                    _lib.query('cvae_persistent_rnn', self._persist_prev)      # back to what it was before the time-out
+        before = (self.iter_num, self.opt.steps, list(self.opt.taken))
         res = self.forward_backward(batch)
         self.opt.step()
-        self.check_kernels()
+        if self.world > 1:
+            pin = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            pin.copy_(self.opt.grads[self.opt.n:self.opt.n + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((ev, pin, batch, before))
+        else:
+            self.check_kernels()
         return res
+
+    def _dp_check(self, lag):
+        """Looks at the reduced status of the step `lag` steps back; handles a time-out (see train_step)."""
+        while len(self._pending) > lag:
+            ev, pin, _, before = self._pending[0]
+            ev.synchronize()
+            if float(pin[0]) == 0.0:
+                self._pending.popleft()
+                continue
+            # some rank timed out in that iteration: its step and the ones enqueued since were skipped on the device.
+            # The host's counters go back to where they stood before it (iteration number -> lambda_KL, Adam's step
+            # counts), so the re-run is the run that would have happened
+            redo = list(self._pending)
+            self._pending.clear()
+            _lib.query('cvae_persist_status')                # drain the device, clear the word
+            prev = _lib.query('cvae_persistent_rnn', 0)
+            if self._cooldown == 0:
+                self._persist_prev = prev
+            self._cooldown = settings.dp_fallback_steps + len(redo) + 1
+            self.iter_num, self.opt.steps, self.opt.taken = before[0], before[1], list(before[2])
+            self.fallbacks.append(before[0] + 1)
+            for _, _, b, _ in redo:
+                self.train_step(b)
+            return
+
+    def dp_flush(self):
+        """End of a data-parallel run (or before reading the weights): every outstanding step is checked."""
+        if self.world > 1:
+            self._dp_check(lag=0)
 
     # ---- evaluation: CV/Experiment.py:1323-1396 ; CC/Experiment.py:538-621
     def iw_eval(self, batches, n_sample):

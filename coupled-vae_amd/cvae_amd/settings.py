@@ -22,6 +22,11 @@ class _Settings(object):
     # data-parallel training: the gradient arena is all-reduced in buckets of about this size,
     #                              each issued (async, on the collective's own stream) as soon as the backward pass has
     #                              produced every gradient in it; 0: one blocking all-reduce after the backward pass
+    dp_persist_headroom = int(os.environ.get('CVAE_DP_HEADROOM_CUS', '8'))
+    # data-parallel training: CUs the whole-sequence recurrent kernels leave free for RCCL's kernels
+    #                              (cvae_persist_headroom); the decoder pair then runs as two launches of 128 blocks
+    dp_fallback_steps = 200   # data-parallel training: steps on the per-timestep kernels after a time-out, before the
+    #                           whole-sequence kernels are tried again (harness.Trainer.train_step)
 
 
 settings = _Settings()

@@ -392,6 +392,18 @@ int cvae_shutdown(void);
  * recurrent kernels: 0 = every in-kernel wait completed; 1 = a bounded spin ran out (results of
  * that call are invalid).  No counterpart in the reference (torch's cuDNN RNN has no such state). */
 int cvae_persist_status(void);
+/* Data-parallel training: *dst = 1.0f if the word is set else 0.0f (export, enqueued); raise the local word if *src is
+ * non-zero (import).  A caller puts the exported float into its gradient all-reduce and imports the reduced value, so
+ * that a time-out on any rank makes cvae_clip_adam skip that step on every rank.  No counterpart in the reference. */
+int cvae_persist_status_export(float* dst, void* stream);
+int cvae_persist_status_import(const float* src, void* stream);
+/* Runtime form of CVAE_PERSISTENT_RNN: 0 = recurrences run on the per-timestep kernels from the next call on (what a
+ * caller switches to after a time-out, without restarting); returns the previous setting. */
+int cvae_persistent_rnn(int on);
+/* CUs the whole-sequence kernels leave free (default 0; env CVAE_PERSIST_HEADROOM): a data-parallel job sets it so
+ * that RCCL's kernels find room beside them; lock-stepped sequences that no longer fit together run as two
+ * launches.  cus < 0 queries; returns the previous value.  No counterpart in the reference. */
+int cvae_persist_headroom(int cus);
 /* The same word read without synchronising or clearing (it lives in host-mapped pinned memory and the kernel
  * that timed out writes it directly): 1 as soon as that store has landed.  Cheap enough to call every training
  * step.  cvae_clip_adam takes its own look at the word on the device and leaves the parameters untouched while

@@ -195,3 +195,95 @@ def test_data_parallel_train_step_two_ranks():
                 solid = P[k].grad.abs() > 1e-3 * P[k].grad.abs().max()
                 assert float(diff[solid].max() / (Q[k].abs().max() + 1e-30)) < 2e-4, (cell, k)
                 assert float(diff.max()) <= 2.001e-3, (cell, k)
+
+
+# ----------------------------------------------------------------------------- a time-out in a data-parallel job
+class _IterNoise(object):
+    """eps that depends only on (iteration, rank): a re-run of an iteration sees the noise of its first attempt."""
+
+    def __new__(cls, tr, rank):
+        from cvae_amd import modules
+
+        class N(modules.NoiseSource):
+            def normal(self, shape, device, name):
+                g = torch.Generator().manual_seed(1000 * tr.iter_num + 10 * rank + (1 if name == 'eps' else 2))
+                return torch.randn(shape, generator=g).to(device)
+        return N()
+
+
+def _fallback_worker(rank, world, port, q):
+    os.environ['CVAE_PERSISTENT_RNN'] = '0'       # two processes share one GPU (see _train_worker)
+    for p in (ROOT, os.path.join(ROOT, 'coupled-vae_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cvae_amd import _lib, data, harness, modules, settings
+        settings.dp_bucket_bytes = 48 << 10
+        settings.dp_fallback_steps = 2
+        dev = torch.device('cuda:0')
+        _lib.init(0)
+        _lib.query('cvae_deterministic', 1)           # bit-reproducible steps: the two runs below must agree exactly
+        V, E, H, Z, Bl = _DP_SHAPE
+        hp = harness.HParams(model='vae-couple', cell='lstm', V=V, E=E, H=H, Z=Z, dropout=0.0, annealing_start=0,
+                             annealing_step=10)
+        n_steps = 8
+        c = data.Corpus(data.synthetic_sentences(world * Bl * n_steps, V, 2.6, 0.5, 30, seed=21))
+        batches = [harness.text_batch(c, range((world * i + rank) * Bl, (world * i + rank + 1) * Bl), dev)
+                   for i in range(n_steps)]
+        out = {}
+        for tag, fail_at in (('clean', None), ('timeout', 3)):
+            tr = harness.Trainer(hp, dev, seed=11)
+            assert _lib.query('cvae_persist_headroom', -1) == settings.dp_persist_headroom
+            modules.set_noise_source(_IterNoise(tr, rank))
+            try:
+                for i, b in enumerate(batches):
+                    if fail_at is not None and i + 1 == fail_at and rank == 1:
+                        torch.cuda.synchronize()
+                        _lib.call('cvae_persist_status_set', 1)      # what a timed-out kernel of THIS rank would do
+                    tr.train_step(b)
+                tr.dp_flush()
+            finally:
+                modules.set_noise_source(None)
+            torch.cuda.synchronize()
+            assert _lib.query('cvae_persist_status') == 0
+            out[tag] = (list(tr.fallbacks), tr.iter_num, tr.opt.steps,
+                        tr.opt.params.detach().cpu().numpy().copy(), (tr._cooldown, _lib.query('cvae_persistent_rnn', 0)))
+        q.put((rank, out))
+    except Exception as e:
+        import traceback
+        q.put((rank, 'ERROR: %s\n%s' % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_timeout_falls_back_on_every_rank():
+    """A whole-sequence kernel times out on ONE rank of a data-parallel job (its status word is raised by hand before
+    iteration 3): the word travels through the gradient all-reduce, so both ranks skip that step on the device, both
+    notice it at the same point two steps later, switch to the per-timestep kernels at run time and re-run the skipped
+    iterations; they report the same fallback iteration, end bit-identical, and -- the host's counters having been
+    rolled back -- end exactly where a run without the time-out ends (deterministic mode)."""
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=200) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert not isinstance(res[r], str), res[r]
+    for r in (0, 1):
+        fb, it, steps, _, persist_on = res[r]['timeout']
+        assert fb == [3], (r, fb)                               # the same iteration on both ranks
+        assert it == 8 and steps == 8, (r, it, steps)           # counters as after 8 applied iterations
+        assert persist_on == (0, 0)                             # cool-down over, the switch back at its previous setting
+        #                                                         (off in this test: CVAE_PERSISTENT_RNN=0, one GPU for two ranks)
+        assert res[r]['clean'][0] == []
+    assert np.array_equal(res[0]['timeout'][3], res[1]['timeout'][3])          # replicas identical
+    assert np.array_equal(res[0]['clean'][3], res[1]['clean'][3])
+    assert np.array_equal(res[0]['timeout'][3], res[0]['clean'][3])            # == the run without the time-out
