@@ -22,9 +22,14 @@ class _Settings(object):
     # data-parallel training: the gradient arena is all-reduced in buckets of about this size,
     #                              each issued (async, on the collective's own stream) as soon as the backward pass has
     #                              produced every gradient in it; 0: one blocking all-reduce after the backward pass
-    dp_persist_headroom = int(os.environ.get('CVAE_DP_HEADROOM_CUS', '8'))
+    dp_persist_headroom = int(os.environ.get('CVAE_DP_HEADROOM_CUS', '0'))
     # data-parallel training: CUs the whole-sequence recurrent kernels leave free for RCCL's kernels
-    #                              (cvae_persist_headroom); the decoder pair then runs as two launches of 128 blocks
+    #                              (cvae_persist_headroom).  Off by default: with any head-room the decoder pair (256
+    #                              blocks) runs as two launches of 128 and the step takes 6.43 instead of 5.31 ms
+    #                              (measured, one GPU); a whole-sequence block fills its CU's register file, so a
+    #                              collective's kernel never shares a CU with one either way -- it runs before or
+    #                              after, the recurrent kernel's blocks wait for theirs (bounded spins, ~0.25 s), and a
+    #                              genuine time-out is handled by Trainer.train_step's fallback
     dp_fallback_steps = 200   # data-parallel training: steps on the per-timestep kernels after a time-out, before the
     #                           whole-sequence kernels are tried again (harness.Trainer.train_step)
 
