@@ -1203,6 +1203,7 @@ int cvae_shutdown(void) { return lib_scratch_release(nullptr, true); }
 int cvae_persist_status_export(float* dst, void* stream) { return launch_status_export(dst, S(stream)); }
 int cvae_persist_status_import(const float* src, void* stream) { return launch_status_import(src, S(stream)); }
 int cvae_persistent_rnn(int on) { return persist_rnn_set(on); }
+int cvae_rnn_large_wreg(int min_rows) { return rnn_large_wreg_set(min_rows); }
 int cvae_persist_headroom(int cus) { return persist_headroom_set(cus); }
 int cvae_persist_status(void) { return persist_status_and_clear(); }
 int cvae_persist_status_peek(void) { return persist_status_peek(); }

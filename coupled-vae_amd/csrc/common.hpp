@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-// Timing-only diagnostic switches (CE_EXP_*, GW_EXP_*, RB_EXP_*: scripts/build_variant.sh) remove work from a kernel to
+// Timing-only diagnostic switches (CE_EXP_*, GW_EXP_*, RB_EXP_*, WR_EXP_*: scripts/build_variant.sh) remove work from a kernel to
 // see what it costs; a library built with any of them computes garbage.  They are accepted only together with
 // -DCVAE_TIMING_BUILD, and every object compiled that way flips the sign of cvae_version(), so that the Python
 // binding (and tests/test_abi_and_host.py) refuse such a library unless CVAE_ALLOW_TIMING_BUILD=1.
@@ -13,7 +13,10 @@
      (defined(GW_EXP_NOSPLIT) && GW_EXP_NOSPLIT) || (defined(GW_EXP_NOMFMA) && GW_EXP_NOMFMA) || \
      (defined(GW_EXP_NOLOAD) && GW_EXP_NOLOAD) || (defined(GW_EXP_NOLDS) && GW_EXP_NOLDS) || \
      (defined(RB_EXP_NOSPLIT) && RB_EXP_NOSPLIT) || (defined(RB_EXP_NOEPI) && RB_EXP_NOEPI) || \
-     (defined(RB_EXP_NOMFMA) && RB_EXP_NOMFMA))
+     (defined(RB_EXP_NOMFMA) && RB_EXP_NOMFMA) || (defined(WR_EXP_NOEPILOAD) && WR_EXP_NOEPILOAD) || \
+     (defined(WR_EXP_NOSTAGELOAD) && WR_EXP_NOSTAGELOAD) || \
+     (defined(WR_EXP_NOMFMA) && WR_EXP_NOMFMA) || (defined(WR_EXP_NOCELL) && WR_EXP_NOCELL) || \
+     (defined(WR_EXP_NOB) && WR_EXP_NOB) || (defined(WR_EXP_STAMPS) && WR_EXP_STAMPS))
 #error "*_EXP_* timing switches need -DCVAE_TIMING_BUILD (the library then reports a negative cvae_version())"
 #endif
 namespace cvae {
@@ -78,7 +81,7 @@ int deterministic_set(int on);   // returns the previous setting
 // Allocated at first use and regrown only when a larger shape arrives (warm-up; hipFree of the old buffer
 // synchronises the device); steady-state calls allocate nothing.  Guarded by a mutex.
 enum LibScratchKind { LS_PERSIST_SYNC = 0, LS_PERSIST_EXCH = 1, LS_WIDE_PART = 2, LS_ROWS = 3, LS_STREAM_IMG = 4,
-                      LS_STREAM_PARTS = 5, LS_SUMSQ = 6, LS_EMB_FIX = 7, LS_KINDS = 8 };
+                      LS_STREAM_PARTS = 5, LS_SUMSQ = 6, LS_EMB_FIX = 7, LS_H_IMAGE = 8, LS_W_IMAGE = 9, LS_KINDS = 10 };
 // zero != 0: a new buffer is zero-filled (synchronously) before it is handed out.  fresh (optional): set when
 // this call (re)allocated.
 int lib_scratch(int kind, hipStream_t s, size_t bytes, void** out, int zero = 0, bool* fresh = nullptr);
@@ -283,6 +286,17 @@ int launch_rnn_backward(const RnnBwd& a, hipStream_t s);
 int launch_rnn_backward_multi(const RnnBwd* a, int ns, hipStream_t s);
 // rnn_large.hip: one step for many rows, gate product + cell in one kernel (IW evaluation)
 bool rnn_large_fused_supported(int cell, int H, const float* h, const float* W_hh);
+// the same step with W_hh resident in registers (LSTM, H = 256 / 512, many rows): reads h_prev as a bf16 (hi, lo) image
+// ([2][img_lo / H rows][H]; launch_rnn_large_split makes one from fp32 rows) and writes h_out's image next to h_out
+bool rnn_large_wreg_supported(int cell, int H, int live, int xmod, int xdiv, const float* h, const float* W_hh);
+size_t rnn_large_image_bytes(int R, int H);
+long rnn_large_image_lo(int R, int H);          // elements from the hi half to the lo half
+int launch_rnn_large_split(const float* h, int rows, int H, void* img, long img_lo, hipStream_t s);
+size_t rnn_large_wimg_bytes(int H);
+int launch_rnn_large_wimg(const float* W_hh, int H, void* wimg, hipStream_t s);       // W_hh -> the kernel's fragment image
+int launch_rnn_large_wreg_step(int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
+                               const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
+                               float* c_out, const void* img_in, void* img_out, long img_lo, hipStream_t s);
 int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const float* c_prev, const float* W_hh,
                           const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
                           float* c_out, hipStream_t s);
@@ -294,6 +308,7 @@ struct ZeroBatch;
 int launch_rnn_forward_persist(const RnnFwd* a, int ns, hipStream_t s, ZeroBatch* zb = nullptr);
 int launch_rnn_backward_persist(const RnnBwd* a, int ns, hipStream_t s);
 int persist_status_and_clear();
+int rnn_large_wreg_set(int min_rows);  // rnn_large.hip: row count from which the weights-in-registers step kernel runs; returns the previous one
 int persist_rnn_set(int on);           // runtime form of CVAE_PERSISTENT_RNN; returns the previous setting
 int persist_headroom_set(int cus);     // CUs left free by the whole-sequence kernels (cus < 0: query); returns the previous value
 

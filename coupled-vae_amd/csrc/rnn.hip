@@ -111,12 +111,34 @@ static void rnn_forward_step_args(const RnnFwd& a, int i, SkinnyArgs& k) {
 static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
   const int G = a.cell == CELL_GRU ? 3 : 4;
   const int xdiv = a.xdiv > 1 ? a.xdiv : 1;
+  // bf16 (hi, lo) images of h for the weights-in-registers step kernel: two (step parity), library scratch
+  char* img[2] = {nullptr, nullptr};
+  void* wimg = nullptr;                   // W_hh as that kernel's register fragments (written once per call)
+  const long img_lo = rnn_large_image_lo(a.R, a.H);
+  bool img_valid = false;                 // img[i & 1] holds the split of step i's h_prev
   for (int i = 0; i < a.T; ++i) {
     SkinnyArgs k;
     rnn_forward_step_args(a, i, k);
     const int live = a.live_rows ? a.live_rows[k.t] : a.R;
     CVAE_REQUIRE(live >= 0 && live <= a.R, "rnn_forward: live_rows[%d]=%d outside [0,%d]", k.t, live, a.R);
     if (live == 0) continue;
+    if (!a.gates && !a.lengths && rnn_large_wreg_supported(a.cell, a.H, live, a.xmod, xdiv, k.A, a.W_hh)) {
+      if (!img[0]) {
+        void* base = nullptr;
+        const size_t one = rnn_large_image_bytes(a.R, a.H);
+        CVAE_TRY(lib_scratch(LS_H_IMAGE, s, 2 * one, &base));
+        img[0] = static_cast<char*>(base);
+        img[1] = img[0] + one;
+        CVAE_TRY(lib_scratch(LS_W_IMAGE, s, rnn_large_wimg_bytes(a.H), &wimg));
+        CVAE_TRY(launch_rnn_large_wimg(a.W_hh, a.H, wimg, s));
+      }
+      if (!img_valid) CVAE_TRY(launch_rnn_large_split(k.h_prev, live, a.H, img[i & 1], img_lo, s));
+      CVAE_TRY(launch_rnn_large_wreg_step(live, a.H, k.h_prev, k.c_prev, wimg, a.b_hh, k.xproj, a.xmod, xdiv, a.xadd,
+                                          k.h_out, k.c_out, img[i & 1], img[(i + 1) & 1], img_lo, s));
+      img_valid = true;
+      continue;
+    }
+    img_valid = false;
     if (!a.gates && !a.lengths && rnn_large_fused_supported(a.cell, a.H, k.A, a.W_hh)) {
       CVAE_TRY(launch_rnn_large_step(a.cell, live, a.H, k.h_prev, k.c_prev, a.W_hh, a.b_hh, k.xproj, a.xmod, xdiv,
                                      a.xadd, k.h_out, k.c_out, s));

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, RL_OCC_) void rnn_large_step_kernel(RnnLargeAr
 // without padding: 2 x (A hi|lo + B hi|lo) = 64 KB, two blocks per CU.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int RB_BK = 32;
 
 // RB_EXP_* : timing-only diagnostic builds (scripts/build_variant.sh), results are wrong with any of them set
@@ -400,6 +401,410 @@ __global__ __launch_bounds__(256, 2) void rnn_large_step_bf3_kernel(RnnLargeArgs
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weights in registers (round 3, LSTM, H = 256 / 512).  The kernel above stages 512 KB through L2 -> LDS for every
+// 128 x 128 output tile (1 GB per 16 000-row step) and runs at the rate of that staging.  Here a block keeps its
+// share of W_hh for the whole launch: 8 waves (two per SIMD); wave (g, uh) holds gate g of 16 of the block's 32 units,
+// all K, as split bf16 B fragments of v_mfma_f32_16x16x32_bf16 in the accumulator half of its registers (H / 32 K
+// blocks x (hi, lo) x 4 = 128 AGPRs at H = 512), and the block walks over 16-row tiles of h (row group rg of nrg:
+// tiles rg, rg + nrg, ...), which are the only operand that moves.
+//  * h arrives already split: the cell of the previous step writes, next to its fp32 h, a bf16 (hi, lo) image of it
+//    (launch_rnn_large_split makes the first one), so a tile is 16 rows x 2 x H bf16 copied global -> LDS by the LDS-DMA
+//    (no registers, no conversions: every one of the H / 32 blocks that share a row group used to redo that split, and
+//    the kernel ran at the rate of its vector instructions); the swizzle that makes every fragment read conflict-free
+//    (slot ^ row) is on the source address.  Double-buffered: tile n+1 lands while tile n is multiplied.
+//  * The H / 32 blocks that share a row group sit on one XCD, so a tile of h reaches that L2 once.
+//  * The four gates of a (row, unit) end up in four waves: they cross through an LDS array X[gate][row][unit]
+//    (double-buffered, one barrier per tile), and the cell runs with lane = unit, one row per thread, one tile behind
+//    (inside the next tile's MFMA loop); its per-row operands (xadd, c) are requested one tile ahead.
+//  * The MFMAs are inline asm: hipcc keeps MFMA A / B operands in VGPRs and would copy every weight fragment out of
+//    the accumulator file before every use.  hi*lo, lo*hi and hi*hi go to three accumulators (independent MFMAs).
+// WR_EXP_* : timing-only diagnostic builds (scripts/build_variant.sh), results are wrong with any of them set
+#ifndef WR_EXP_NOEPILOAD
+#define WR_EXP_NOEPILOAD 0
+#endif
+#ifndef WR_EXP_NOSTAGELOAD
+#define WR_EXP_NOSTAGELOAD 0
+#endif
+#ifndef WR_EXP_NOMFMA
+#define WR_EXP_NOMFMA 0
+#endif
+#ifndef WR_EXP_NOCELL
+#define WR_EXP_NOCELL 0
+#endif
+#ifndef WR_EXP_NOB
+#define WR_EXP_NOB 0
+#endif
+#ifndef WR_PF_
+#define WR_PF_ 2
+#endif
+#ifndef WR_EXP_STAMPS
+#define WR_EXP_STAMPS 0
+#endif
+#if WR_EXP_STAMPS
+#define WR_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sacc_[k] += (unsigned)(now_ - tprev_); tprev_ = now_; } while (0)
+#else
+#define WR_STAMP(k) do {} while (0)
+#endif
+constexpr int WR_THREADS = 512, WR_ROWS = 16, WR_PF = WR_PF_;
+
+struct RnnWregArgs {
+  RnnLargeArgs a;
+  const __bf16* img_in;      // [hi | lo][img_rows][H]: bf16 split of h_prev
+  __bf16* img_out;           // the same for h_out (written by the cell)
+  long img_lo;               // elements from the hi image to the lo image
+  int nrg;                   // row groups
+  const i32x4* wimg;         // W_hh as this kernel's B fragments: [H / 32 column groups][8 waves][K block][hi | lo][64 lanes]
+};
+
+// fp32 rows -> (hi, lo) bf16 image (the first step's h; 8 elements per thread)
+__global__ __launch_bounds__(256) void rnn_large_split_kernel(long n8, const float* __restrict__ h, __bf16* __restrict__ img,
+                                                              long img_lo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  bf16x8 hi, lo;
+  rb_split(*reinterpret_cast<const f32x4*>(h + 8 * i), *reinterpret_cast<const f32x4*>(h + 8 * i + 4), hi, lo);
+  *reinterpret_cast<bf16x8*>(img + 8 * i) = hi;
+  *reinterpret_cast<bf16x8*>(img + img_lo + 8 * i) = lo;
+}
+
+// W_hh -> the B fragments of rnn_large_wreg_kernel, in the order its waves load them (once per decoder call: the
+// step kernel then fills its registers with 1 KB-contiguous loads instead of re-splitting its share at every step)
+__global__ __launch_bounds__(WR_THREADS) void rnn_large_wimg_kernel(int H, const float* __restrict__ W_hh, i32x4* __restrict__ wimg) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int gate = wave & 3, uh = wave >> 2, cg = blockIdx.x, nkb = H / 32;
+  const float* wrow = W_hh + (long)(gate * H + cg * 32 + 16 * uh + l15) * H + 8 * kq;
+  i32x4* dst = wimg + (size_t)(cg * 8 + wave) * nkb * 2 * 64 + lane;
+  for (int kb = 0; kb < nkb; ++kb) {
+    bf16x8 hi, lo;
+    rb_split(*reinterpret_cast<const f32x4*>(wrow + 32 * kb), *reinterpret_cast<const f32x4*>(wrow + 32 * kb + 4), hi, lo);
+    dst[(kb * 2 + 0) * 64] = __builtin_bit_cast(i32x4, hi);
+    dst[(kb * 2 + 1) * 64] = __builtin_bit_cast(i32x4, lo);
+  }
+}
+
+template <int NKB, bool XADD>                                 // K blocks of 32: H = 32 NKB
+__global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs w) {
+  const RnnLargeArgs& p = w.a;
+  constexpr int H = NKB * 32, GH = 4 * H, SLOTS = H / 8;      // 16-byte slots per row of an image
+  constexpr int IMG = WR_ROWS * SLOTS;                        // slots of one image (hi or lo) of a 16-row tile
+  constexpr int SEGS = IMG / 64;                              // DMA pieces (64 slots = 1 KB) per image
+  constexpr int PW = 2 * SEGS / 8;                            // ... per wave and tile: 4 (H 512), 2 (H 256)
+  constexpr int XSZ = 4 * WR_ROWS * 32;
+  extern __shared__ __attribute__((aligned(16))) float rl_smem[];
+  bf16x8* sm = reinterpret_cast<bf16x8*>(rl_smem);            // [buf][hi | lo][IMG]
+  float* X = rl_smem + 4 * IMG * 4;                           // [buf][gate][row][unit]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // the same number, provably wave-uniform (scalar address math)
+  const int l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15, kq = lane >> 4;
+  const int gate = wave & 3, uh = wave >> 2;
+  constexpr int ncg = H / 32;
+  const int nrg = w.nrg;
+  const int b = blockIdx.x, idx = b >> 3;
+  const int cg = idx % ncg, rg = (b & 7) + 8 * (idx / ncg);
+  const int u0 = cg * 32, u = u0 + l31;
+  const int ntiles = (p.live + WR_ROWS - 1) / WR_ROWS;
+  if (rg >= ntiles) return;
+#if WR_EXP_STAMPS
+  const unsigned long long t00_ = __builtin_amdgcn_s_memtime();
+#endif
+  const int nt = (ntiles - rg + nrg - 1) / nrg;
+  const int last_row = p.live - 1;
+
+  // DMA piece j of this wave: 64 consecutive slots of one image of the tile; this lane's slot q = (row r, position ps)
+  // receives logical slot ps ^ r of that row.  Rows past the live prefix are read as they are (the images are padded
+  // to whole tiles; a row's garbage stays in that row of the product, which is never stored).
+  unsigned dma_voff[PW];                                      // byte offset of the lane's 16 bytes from the tile's first row
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int pc = wave * PW + j, im = pc / SEGS, q = (pc % SEGS) * 64 + lane;
+    const int r = q / SLOTS, ps = q % SLOTS;
+    dma_voff[j] = (unsigned)(im * w.img_lo * 2 + r * (H * 2) + 16 * (ps ^ r));
+  }
+  auto stage_dma = [&](int j, int n, int buf) {               // buf: compile-time or scalar
+#if !WR_EXP_NOSTAGELOAD
+    const int row0 = (rg + nrg * min(n, nt - 1)) * WR_ROWS;   // scalar
+    const char* base = reinterpret_cast<const char*>(w.img_in) + (size_t)row0 * (H * 2);
+    const int pc = wave_u * PW + j;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_voff[j]),
+                                     (__attribute__((address_space(3))) void*)(sm + buf * 2 * IMG + (pc / SEGS) * IMG + (pc % SEGS) * 64),
+                                     16, 0, 0);
+#endif
+  };
+#pragma unroll
+  for (int j = 0; j < PW; ++j) stage_dma(j, 0, 0);
+
+  // this wave's weights: gate `gate`, units u0 + 16 uh + (0..15), as B fragments (lane: unit l15, k = 32 kb + 8 kq + 0..7),
+  // from the image rnn_large_wimg_kernel wrote
+  i32x4 bh[NKB], bl[NKB];
+  {
+    const i32x4* src = w.wimg + (size_t)(cg * 8 + wave_u) * NKB * 2 * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#if WR_EXP_NOB
+      bh[kb] = i32x4{kb, lane, 3, 4}; bl[kb] = i32x4{kb, 1, lane, 4}; (void)src;
+#else
+      bh[kb] = src[(kb * 2 + 0) * 64];
+      bl[kb] = src[(kb * 2 + 1) * 64];
+#endif
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+a"(bh[kb]), "+a"(bl[kb]));       // from here on accumulator-file tuples
+  }
+  float bq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bq[g] = p.b_hh[g * H + u];
+
+  // The cell's row of a tile: m0 + 2 wave + lhi, unit u.  Its operands are addressed as (scalar base) + (32-bit lane
+  // offset): one multiply-add per array instead of 64-bit arithmetic per load -- the kernel's vector issue is as busy
+  // as its matrix pipe.  xadd and c of tile n+1 are requested during tile n.
+  const int crow = wave * 2 + lhi;
+  const float inv_xdiv = 1.f / (float)p.xdiv;
+  const char* xadd_b = reinterpret_cast<const char*>(p.xadd);
+  const char* xproj_b = reinterpret_cast<const char*>(p.xproj);
+  const char* cprev_b = reinterpret_cast<const char*>(p.c_prev);
+  auto ldf = [](const char* base, unsigned off) { return *reinterpret_cast<const float*>(base + off); };
+  float xa[4], cp;
+  auto cell_prefetch = [&](int n) {
+    const int mc = min((rg + nrg * min(n, nt - 1)) * WR_ROWS + crow, last_row);
+#if WR_EXP_NOEPILOAD
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xa[g] = 0.1f * g + 1e-6f * mc;
+    cp = 0.25f;
+#else
+    if constexpr (XADD) {
+      const unsigned o = (unsigned)(mc * GH + u) * 4u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xa[g] = ldf(xadd_b, o + g * (H * 4));
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xa[g] = 0.f;
+    }
+    cp = ldf(cprev_b, (unsigned)(mc * H + u) * 4u);
+#endif
+  };
+  cell_prefetch(0);
+  __syncthreads();                                            // tile 0's image has landed (the barrier drains the DMA)
+
+  // fragment reads: slot (4 kb + kq) ^ l15 of row l15 = 16 (kb >> 2) + 4 ((kb & 3) ^ (l15 >> 2)) + (kq ^ (l15 & 3)):
+  // four lane addresses (kb & 3), everything else is the instruction's immediate offset
+  const bf16x8* fr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) fr[q] = sm + l15 * SLOTS + 4 * (q ^ (l15 >> 2)) + (kq ^ (l15 & 3));
+  float* const xw = X + (gate * WR_ROWS + 4 * kq) * 32 + 16 * uh + l15;      // + r * 32: this lane's accumulator rows
+  const float* const xr = X + crow * 32 + l31;                              // + g * WR_ROWS * 32: this thread's cell
+#if WR_EXP_STAMPS
+  unsigned sacc_[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart_ = tprev_;
+#endif
+  // the cell of tile n-1 runs inside the MFMA loop of tile n (one tile behind: the matrix pipe has work while the
+  // activations are computed): its summed pre-activations, its c and its output offset travel in pre / cprev / oprev
+  float pre[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+  unsigned oprev = 0;
+  bool vprev = false;                                         // no row yet
+  char* hout_b = reinterpret_cast<char*>(p.h_out);
+  char* cout_b = reinterpret_cast<char*>(p.c_out);
+  char* ihi_b = reinterpret_cast<char*>(w.img_out);
+  char* ilo_b = reinterpret_cast<char*>(w.img_out + w.img_lo);
+  auto cell_finish = [&]() {
+    const float ig = sigmoid_fast(pre[0]);
+    const float fg = sigmoid_fast(pre[1]);
+    const float gg = tanh_fast(pre[2]);
+    const float og = sigmoid_fast(pre[3]);
+    const float cnew = fg * cprev + ig * gg;
+    const float hnew = og * tanh_fast(cnew);
+    const __bf16 hh = (__bf16)hnew;
+    const __bf16 hl = (__bf16)(hnew - (float)hh);
+    if (vprev) {
+      *reinterpret_cast<float*>(hout_b + oprev) = hnew;
+      *reinterpret_cast<float*>(cout_b + oprev) = cnew;
+      *reinterpret_cast<__bf16*>(ihi_b + (oprev >> 1)) = hh;
+      *reinterpret_cast<__bf16*>(ilo_b + (oprev >> 1)) = hl;
+    }
+  };
+  for (int n = 0; n < nt; ++n) {
+    WR_STAMP(4);
+    const int m = (rg + nrg * n) * WR_ROWS + crow;
+    const int mc = min(m, last_row);
+    float x[4], cc = cp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x[g] = xa[g];
+    // these copies are the last use of an ordinary load's result before the barrier: while an LDS-DMA is in flight
+    // hipcc drains the whole queue (vmcnt(0)) at any such use, so the DMA is issued after them
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(cc));
+    WR_STAMP(5);
+    float xq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    const int boff = (n & 1) * 2 * IMG;                        // scalar: this tile's buffer
+    // A fragments WR_PF K blocks ahead of their MFMAs (a ring of WR_PF + 1 register sets)
+    i32x4 fh[WR_PF + 1], fl[WR_PF + 1];
+#pragma unroll
+    for (int d = 0; d < WR_PF; ++d) {
+      fh[d] = __builtin_bit_cast(i32x4, fr[d & 3][boff + 16 * (d >> 2)]);
+      fl[d] = __builtin_bit_cast(i32x4, fr[d & 3][boff + IMG + 16 * (d >> 2)]);
+    }
+    WR_STAMP(0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      // memory instructions of the tile, spread over the MFMA loop: the other buffer's DMA (its readers passed barrier
+      // n-1), the sentence-shared x-side pre-activations (L2-resident), the next tile's per-row operands, the cell of
+      // the previous tile
+      if (kb < PW) stage_dma(kb, n + 1, (n + 1) & 1);
+#if !WR_EXP_NOEPILOAD
+      if (kb == PW) {
+        int q = (int)((float)mc * inv_xdiv);                  // mc / xdiv (< xmod: checked by the launcher): float estimate, then exact
+        const int rem = mc - q * p.xdiv;
+        q += rem >= p.xdiv ? 1 : (rem < 0 ? -1 : 0);
+        const unsigned o = (unsigned)(q * GH + u) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xq[g] = ldf(xproj_b, o + g * (H * 4));
+      }
+#endif
+      if (kb == PW + 1) cell_prefetch(n + 1);
+#if !WR_EXP_NOCELL
+      if (kb == PW + 3) cell_finish();                        // tile n-1
+#endif
+      if (kb + WR_PF < NKB) {
+        constexpr int dummy = 0; (void)dummy;
+        const int k2 = kb + WR_PF;
+        fh[k2 % (WR_PF + 1)] = __builtin_bit_cast(i32x4, fr[k2 & 3][boff + 16 * (k2 >> 2)]);
+        fl[k2 % (WR_PF + 1)] = __builtin_bit_cast(i32x4, fr[k2 & 3][boff + IMG + 16 * (k2 >> 2)]);
+      }
+      const i32x4 ah = fh[kb % (WR_PF + 1)], al = fl[kb % (WR_PF + 1)];
+      // s_nop 1: a just-written VGPR operand -> MFMA
+#if WR_EXP_NOMFMA
+      acc0[kb & 3] += __builtin_bit_cast(f32x4, ah)[0] + __builtin_bit_cast(f32x4, al)[1];
+      if (false)
+#endif
+      asm volatile("s_nop 1\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %0, %3, %6, %0\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %1, %4, %5, %1\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %2, %3, %5, %2"
+                   : "+v"(acc0), "+v"(acc1), "+v"(acc2) : "v"(ah), "v"(al), "a"(bh[kb]), "a"(bl[kb]));
+    }
+    asm volatile("s_nop 15" : "+v"(acc0), "+v"(acc1), "+v"(acc2));      // MFMA result -> any other reader: wait states
+    WR_STAMP(1);
+    const f32x4 acc = (acc0 + acc1) + acc2;
+#if WR_EXP_NOCELL
+    if (m < p.live) p.h_out[(long)m * H + u] = acc[0] + acc[3] + x[0] + x[1] + x[2] + x[3] + cc + xq[0] + xq[3];
+    __syncthreads();
+    continue;
+#endif
+    // acc[r] = gate `gate` of row 4 kq + r, unit 16 uh + l15
+    const int xoff = (n & 1) * XSZ;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xw[xoff + r * 32] = acc[r];
+    // one barrier per tile: X(n) complete; the other buffer's image landed (hipcc drains an LDS-DMA in flight at a
+    // barrier); this buffer's reads over.  X is double-buffered: X(n+2) is written after barrier n+1, which every
+    // wave passes only after it has read X(n).
+    __syncthreads();
+    WR_STAMP(2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = xr[xoff + g * WR_ROWS * 32] + ((x[g] + xq[g]) + bq[g]);
+    cprev = cc;
+    oprev = (unsigned)(mc * H + u) * 4u;
+    vprev = m < p.live;
+    WR_STAMP(3);
+  }
+#if !WR_EXP_NOCELL
+  cell_finish();
+#endif
+#if WR_EXP_STAMPS
+  if ((blockIdx.x == 0 || blockIdx.x == 100) && (tid == 0 || tid == 448))
+    printf("wreg stamps block %d tid %d: tiles %d, prologue %u, per tile: copies %u, top %u, kloop %u, barrier %u, cell %u, back-edge %u (s_memtime ticks)\n",
+           (int)blockIdx.x, tid, nt, (unsigned)(tstart_ - t00_), sacc_[5] / nt, sacc_[0] / nt, sacc_[1] / nt, sacc_[2] / nt, sacc_[3] / nt, sacc_[4] / nt);
+#endif
+}
+
+// rows below which the 128-row-tile kernel is the faster one (too few 16-row tiles per row group); env
+// CVAE_RNN_LARGE_WREG_MIN, CVAE_RNN_LARGE_WREG=0 turns the kernel off; cvae_rnn_large_wreg() is the runtime form
+static int g_wreg_min = -1;
+static int wreg_min_rows() {
+  if (g_wreg_min < 0) {
+    const char* e = getenv("CVAE_RNN_LARGE_WREG_MIN");
+    g_wreg_min = e ? atoi(e) : 64;
+    const char* on = getenv("CVAE_RNN_LARGE_WREG");
+    if (on && on[0] == '0') g_wreg_min = 1 << 30;
+  }
+  return g_wreg_min;
+}
+int rnn_large_wreg_set(int min_rows) {
+  const int prev = wreg_min_rows();
+  if (min_rows >= 0) g_wreg_min = min_rows;
+  return prev;
+}
+
+// (xmod, xdiv): the kernel takes row r's x-side row as r / xdiv, so every live row must lie below xdiv * xmod; its
+// 32-bit byte offsets need live * 4H * 4 < 2^32
+bool rnn_large_wreg_supported(int cell, int H, int live, int xmod, int xdiv, const float* h, const float* W_hh) {
+  return split_bf16_enabled() && cell == CELL_LSTM && (H == 512 || H == 256) && live >= wreg_min_rows() &&
+         (long)live <= (long)xmod * xdiv && (long)live * 16 * H < (1L << 32) &&
+         aligned16(h) && aligned16(W_hh) && persistent_grid_blocks() / 2 / (H / 32) >= 8;
+}
+
+// an image pair of R rows: each half padded to whole 16-row tiles (the kernel's DMA reads whole tiles)
+long rnn_large_image_lo(int R, int H) { return (long)((R + WR_ROWS - 1) / WR_ROWS * WR_ROWS) * H; }
+size_t rnn_large_image_bytes(int R, int H) { return (size_t)2 * rnn_large_image_lo(R, H) * sizeof(__bf16); }
+
+// (hi, lo) image of rows [0, rows) of h ([rows, H] fp32); img_lo = elements between the two halves of the image
+int launch_rnn_large_split(const float* h, int rows, int H, void* img, long img_lo, hipStream_t s) {
+  CVAE_REQUIRE(h && img && rows > 0 && H % 8 == 0 && aligned16(h) && aligned16(img) && img_lo % 8 == 0, "rnn_large_split: bad argument");
+  const long n8 = (long)rows * H / 8;
+  hipLaunchKernelGGL(rnn_large_split_kernel, dim3((unsigned)cdiv(n8, 256)), dim3(256), 0, s, n8, h, static_cast<__bf16*>(img), img_lo);
+  CVAE_LAUNCH_CHECK("rnn_large_split_kernel");
+  return 0;
+}
+
+size_t rnn_large_wimg_bytes(int H) { return (size_t)4 * H * H * 4; }      // 4H x H (hi, lo) bf16
+
+// W_hh ([4H, H] fp32) -> the step kernel's fragment image
+int launch_rnn_large_wimg(const float* W_hh, int H, void* wimg, hipStream_t s) {
+  CVAE_REQUIRE(W_hh && wimg && (H == 512 || H == 256) && aligned16(W_hh) && aligned16(wimg), "rnn_large_wimg: bad argument");
+  hipLaunchKernelGGL(rnn_large_wimg_kernel, dim3(H / 32), dim3(WR_THREADS), 0, s, H, W_hh, static_cast<i32x4*>(wimg));
+  CVAE_LAUNCH_CHECK("rnn_large_wimg_kernel");
+  return 0;
+}
+
+// one step of rows [0, live) on the weights-in-registers kernel; img_in = split image of h_prev, img_out receives h_out's;
+// wimg = launch_rnn_large_wimg's image of W_hh
+int launch_rnn_large_wreg_step(int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
+                               const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
+                               float* c_out, const void* img_in, void* img_out, long img_lo, hipStream_t s) {
+  if (live <= 0) return 0;
+  CVAE_REQUIRE(h_prev && c_prev && wimg && b_hh && xproj && h_out && c_out && img_in && img_out && xmod > 0 && xdiv > 0,
+               "rnn_large_wreg_step: null operand");
+  CVAE_REQUIRE(H == 512 || H == 256, "rnn_large_wreg_step: H=%d (256 or 512)", H);
+  CVAE_REQUIRE(aligned16(img_in) && aligned16(img_out) && img_lo % 8 == 0 && img_lo >= rnn_large_image_lo(live, H),
+               "rnn_large_wreg_step: image misaligned or too small");
+  CVAE_REQUIRE((long)live <= (long)xmod * xdiv && (long)live * 16 * H < (1L << 32), "rnn_large_wreg_step: rows beyond xdiv * xmod or 32-bit offsets");
+  const int ncg = H / 32, nrg = persistent_grid_blocks() / 2 / ncg / 8 * 8;     // row groups: one block per CU
+  CVAE_REQUIRE(nrg >= 8, "rnn_large_wreg_step: %d CUs are too few", persistent_grid_blocks() / 2);
+  RnnWregArgs a = {{h_prev, c_prev, nullptr, b_hh, xproj, xadd, h_out, c_out, live, H, xmod, xdiv},
+                   static_cast<const __bf16*>(img_in), static_cast<__bf16*>(img_out), img_lo, nrg,
+                   static_cast<const i32x4*>(wimg)};
+  ProfScope prof(PK_RNN_LARGE, s, 2.0 * live * 4 * H * (double)H);
+  const dim3 gridw(ncg * nrg);
+  const size_t ldsw = (size_t)4 * WR_ROWS * (H / 8) * 16 + 2 * 4 * WR_ROWS * 32 * sizeof(float);     // 80 KB (H 512) / 48 KB
+  static bool attrw = false;
+  if (!attrw) {
+    const void* fs[4] = {reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, true>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, false>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, true>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, false>)};
+    for (const void* f : fs)
+      CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "rnn_large wreg LDS attribute"));
+    attrw = true;
+  }
+  const dim3 blockw(WR_THREADS);
+  if (H == 512 && xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, true>), gridw, blockw, ldsw, s, a);
+  else if (H == 512) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, false>), gridw, blockw, ldsw, s, a);
+  else if (xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<8, true>), gridw, blockw, ldsw, s, a);
+  else hipLaunchKernelGGL((rnn_large_wreg_kernel<8, false>), gridw, blockw, ldsw, s, a);
+  CVAE_LAUNCH_CHECK("rnn_large_wreg_kernel");
+  return 0;
 }
 
 bool rnn_large_fused_supported(int cell, int H, const float* h, const float* W_hh) {

@@ -27,6 +27,7 @@ SIGNATURES = {
     'cvae_version': [],
     'cvae_release_stream': [P],
     'cvae_persistent_rnn': [I],
+    'cvae_rnn_large_wreg': [I],
     'cvae_persist_status_export': [P, P],
     'cvae_persist_status_import': [P, P],
     'cvae_persist_headroom': [I],

@@ -6,7 +6,7 @@ import torch
 from cvae_amd import _lib, data, harness
 dev = torch.device('cuda:0'); _lib.init(0)
 cell = sys.argv[1] if len(sys.argv) > 1 else 'lstm'
-shape = dict(data.SHAPES['yelp'])
+shape = dict(data.SHAPES[os.environ.get('SHAPE', 'yelp')])
 if len(sys.argv) > 2:
     shape['V'] = int(sys.argv[2])       # smaller vocab = less GPU work at equal launch count
 hp = harness.HParams(model='vae-couple', cell=cell, V=shape['V'], E=shape['E'], H=shape['H'], Z=shape['Z'])
