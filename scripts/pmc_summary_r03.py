@@ -23,6 +23,7 @@ KEYS = collections.OrderedDict([
     ('ce_grad_from_logits_kernel', lambda n: 'ce_grad_from_logits_kernel' in n),
     ('iw_reduce_kernel', lambda n: 'iw_reduce_kernel' in n),
     ('rnn_large_step_bf3_kernel', lambda n: 'rnn_large_step_bf3_kernel' in n),
+    ('rnn_large_wreg_kernel', lambda n: 'rnn_large_wreg_kernel' in n),
     ('gemm_wide_bf3_kernel', lambda n: 'gemm_wide_bf3_kernel' in n),
     ('gemm_nt_bf3_kernel', lambda n: 'gemm_nt_bf3' in n),
     ('rnn_fwd_persist_tag_kernel', lambda n: 'rnn_fwd_persist_tag_kernel' in n),
