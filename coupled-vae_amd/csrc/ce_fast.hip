@@ -351,9 +351,14 @@ __device__ __forceinline__ void bf3_split(f32x8 v, bf16x8& hi, bf16x8& lo) {
   lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
 }
 
+// scale / bias (evaluation launch, ce_core_bf3_kernel<.., FAST>): every entry times `scale` (log2 e: the kernel's
+// softmax then runs on v_exp_f32 without a multiply), and column k = E of the image -- a K slot the 16-wide blocks
+// leave free when E is not a multiple of 16 -- holds scale * bias[v] (the rows carry 1.0 there: the bias comes out of
+// the product), -1e30 for the rows past V (exp2 of it is 0: no masking in the kernel)
 template <int NB>
 __global__ __launch_bounds__(256) void ce_presplit_kernel(int V, int E, const float* __restrict__ W, int vec,
-                                                          bf16x8* __restrict__ Wp) {
+                                                          bf16x8* __restrict__ Wp, float scale = 1.f,
+                                                          const float* __restrict__ bias = nullptr) {
   constexpr int LDR8 = 2 * NB + 1;                       // bf16x8 units per LDS row
   const int ntiles = (V + CE_TN - 1) / CE_TN;
   const long total = (long)ntiles * CE_TN * LDR8;
@@ -373,6 +378,15 @@ __global__ __launch_bounds__(256) void ce_presplit_kernel(int V, int E, const fl
         for (int j = 0; j < 8; ++j) if (k + j < E) x[j] = src[j];
       }
     }
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] *= scale;
+      if (E >= k && E < k + 8) {
+        const float bv = v < V ? scale * bias[v] : -1e30f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k + j == E) x[j] = bv;
+      }
+    }
     bf16x8 hi, lo;
     bf3_split(x, hi, lo);
     bf16x8* t = Wp + (long)tile * 2 * CE_TN * LDR8;
@@ -381,8 +395,25 @@ __global__ __launch_bounds__(256) void ce_presplit_kernel(int V, int E, const fl
   }
 }
 
-template <int NB, bool GRAD, bool SAVE>
+// FAST (the evaluation launch: no GRAD, no SAVE, E < 16 NB): W's image is pre-scaled by log2 e and carries the bias
+// in K slot E (ce_presplit_kernel), so a tile's epilogue is max / subtract / v_exp_f32 / add per logit and nothing
+// else -- no bias add, no -inf masking, no multiply, and the target's logit is looked for only in the tile that holds
+// it.  The kernel's two waves per SIMD keep the vector issue port as busy as the matrix pipe: the epilogue's
+// instruction count is what its speed hangs on.  (m, target logit) go back to natural units when they are stored.
+#ifdef CE_EXP_STAMPS
+#define CE_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sacc_[k] += (unsigned)(now_ - tprev_); tprev_ = now_; } while (0)
+#else
+#define CE_STAMP(k) do {} while (0)
+#endif
+template <int NB, bool GRAD, bool SAVE, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf16x8* __restrict__ Wp) {
+  static_assert(!FAST || (!GRAD && !SAVE), "FAST is the evaluation form");
+#ifdef CE_EXP_STAMPS
+  unsigned long long sacc_[5] = {0, 0, 0, 0, 0};
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long tbeg_ = tprev_, rbeg_ = __builtin_amdgcn_s_memrealtime();
+  unsigned ntl_ = 0;
+#endif
   constexpr int LDR8 = 2 * NB + 1;
   constexpr int TILE8 = 2 * CE_TN * LDR8;        // bf16x8 units per tile (hi block + lo block)
   constexpr int NST = (TILE8 + 255) / 256;
@@ -403,25 +434,30 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
   const int nsplit = ce_pick_split(rb, ntiles, p.cap, gridDim.x);
   const int tps = (ntiles + nsplit - 1) / nsplit;
 
-  bf16x8 st[NST];
+  // A tile of W's image (already in LDS order: ce_presplit_kernel) is copied global -> LDS by the LDS-DMA, one 1 KB
+  // piece per wave-instruction, issued when the previous tile's barrier has released the other buffer; it lands
+  // while this tile is multiplied (hipcc drains it at the next barrier).  Staging through registers cost every wave
+  // 7 ds_write_b128 per tile: 55 KB per CU and tile pair through the LDS store path (~79 B/clk) = ~700 cycles in
+  // which no wave of the CU issued an MFMA (both blocks of a CU run in phase).
+  static_assert(TILE8 % 64 == 0, "whole DMA pieces");
+  constexpr int NPC = TILE8 / 64;
+  (void)NST;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   float bst = 0.f;
-  auto stage_load = [&](int tile) {
-    const bf16x8* src = Wp + (long)tile * TILE8;
+  auto stage_load = [&](int tile, int buf) {
+    const bf16x8* src = Wp + (long)tile * TILE8 + lane;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int idx = tid + 256 * i;
-      if (NST * 256 == TILE8 || idx < TILE8) st[i] = src[idx];
+    for (int j = 0; j < (NPC + 3) / 4; ++j) {
+      const int pc = wave_u + 4 * j;
+      if (pc < NPC)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
+                                         (__attribute__((address_space(3))) void*)(&Wt[buf][pc * 64]), 16, 0, 0);
     }
     const int n0 = tile * CE_TN;
-    if (tid < CE_TN) bst = (n0 + tid < p.V) ? p.bias[n0 + tid] : -INFINITY;
+    if (!FAST && tid < CE_TN) bst = (n0 + tid < p.V) ? p.bias[n0 + tid] : -INFINITY;
   };
   auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int idx = tid + 256 * i;
-      if (NST * 256 == TILE8 || idx < TILE8) Wt[buf][idx] = st[i];
-    }
-    if (tid < CE_TN) Bt[buf][tid] = bst;
+    if (!FAST && tid < CE_TN) Bt[buf][tid] = bst;
   };
 
   for (int item = blockIdx.x; item < rb * nsplit; item += gridDim.x) {
@@ -442,6 +478,10 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
         if (rv && 16 * Q + 8 * lhi < p.E) {       // E % 8 == 0 and 16-byte rows (host-checked): whole groups of 8
           const float4 a = *reinterpret_cast<const float4*>(xr + 16 * Q), b = *reinterpret_cast<const float4*>(xr + 16 * Q + 4);
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        if (FAST) {                                 // the bias slot: 1.0 at k = E
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (16 * Q + 8 * lhi + j == p.E) v[j] = 1.f;
         }
         bf3_split(v, xh[Q], xl[Q]);
       }
@@ -464,14 +504,15 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
     }
     if (SAVE) prow = p.P + (long)ci * p.ldp;
 
-    stage_load(t0);
+    stage_load(t0, 0);
     stage_store(0);
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
       const int buf = (t - t0) & 1;
       const int n0 = t * CE_TN;
+      CE_STAMP(3);
 #ifndef CE_EXP_NOLOAD
-      if (t + 1 < t1) stage_load(t + 1);
+      if (t + 1 < t1) stage_load(t + 1, buf ^ 1);
 #endif
       f32x16 acc;
 #pragma unroll
@@ -500,7 +541,46 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[Q], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      CE_STAMP(0);
       // acc[r] = logit(row = this lane's, vocab column n0 + j), j = (r & 3) + 8 * (r >> 2) + 4 * lhi
+      if constexpr (FAST) {                       // base-2 logits, bias included, columns past V at -1e30
+        // (asm: fmaxf on MFMA results costs a canonicalising v_max per operand.  hipcc pads no hazard inside an asm
+        // statement: the wait states from the last MFMA to the first reader of its result open the string)
+        float mx;
+        asm volatile("s_nop 15\n\ts_nop 3\n\t"
+                     "v_max3_f32 %0, %1, %2, %3\n\t"
+                     "v_max3_f32 %0, %0, %4, %5\n\t"
+                     "v_max3_f32 %0, %0, %6, %7\n\t"
+                     "v_max3_f32 %0, %0, %8, %9\n\t"
+                     "v_max3_f32 %0, %0, %10, %11\n\t"
+                     "v_max3_f32 %0, %0, %12, %13\n\t"
+                     "v_max3_f32 %0, %0, %14, %15\n\t"
+                     "v_max3_f32 %0, %0, %16, %17"
+                     : "=&v"(mx)
+                     : "v"(m), "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]),
+                       "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]),
+                       "v"(acc[14]), "v"(acc[15]));
+        const float mn = mx;
+        float sum = s * __builtin_amdgcn_exp2f(m - mn);                               // m = -inf at first: 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(acc[r] - mn);
+        s = sum;
+        m = mn;
+        if (__builtin_amdgcn_ballot_w64((unsigned)(tg - n0) < (unsigned)CE_TN) != 0) {  // some row's target is in this tile
+          const int jt = tg - n0 - 4 * lhi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (jt == (r & 3) + 8 * (r >> 2)) { tlv = acc[r]; found = true; }
+        }
+        CE_STAMP(1);
+        if (t + 1 < t1) stage_store(buf ^ 1);
+        CE_STAMP(2);
+        __syncthreads();
+#ifdef CE_EXP_STAMPS
+        ++ntl_;
+#endif
+        continue;
+      }
       float xv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -550,7 +630,12 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
       if (t + 1 < t1) stage_store(buf ^ 1);
       __syncthreads();
     }
+    CE_STAMP(4);
     if (!GRAD) {
+      if (FAST) {                                 // back to natural units: s is a sum of e^(x - m) either way
+        m *= 0.6931471805599453f;
+        tlv *= 0.6931471805599453f;
+      }
       const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(s, 32, 64);
       lse_merge2(m, s, m2, s2);
       if (rv) {
@@ -562,6 +647,13 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
       }
     }
   }
+#ifdef CE_EXP_STAMPS
+  if (FAST && (blockIdx.x == 0 || blockIdx.x == 300) && (tid == 0 || tid == 192) && ntl_ > 1000)
+    printf("ce stamps block %d tid %d: tiles %u, per tile: mfma %llu, epilogue %llu, stage_store %llu, barrier+top %llu; per item other %llu; clock %.0f MHz over %.2f ms\n",
+           (int)blockIdx.x, tid, ntl_, sacc_[0] / ntl_, sacc_[1] / ntl_, sacc_[2] / ntl_, sacc_[3] / ntl_, sacc_[4],
+           100.0 * (double)(__builtin_amdgcn_s_memtime() - tbeg_) / (double)(__builtin_amdgcn_s_memrealtime() - rbeg_),
+           (double)(__builtin_amdgcn_s_memrealtime() - rbeg_) / 1e5);
+#endif
 }
 
 __global__ __launch_bounds__(256) void ce_combine2_kernel(CeArgs p, int nblk, float* __restrict__ loss,
@@ -674,9 +766,25 @@ static int launch_core(const CeArgs& a, hipStream_t s, float* presplit_ws = null
     const long units = (long)cdiv(a.V, CE_TN) * CE_TN * (2 * nb + 1);
     int pg = (int)((units + 255) / 256);
     if (pg > 4096) pg = 4096;
+    // the evaluation form (FAST) needs a free K slot for the bias: E < 16 nb; env CVAE_CE_FAST_EVAL=0 turns it off
+    static int fast_on = -1;
+    if (fast_on < 0) {
+      const char* e = getenv("CVAE_CE_FAST_EVAL");
+      fast_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool fast = !GRAD && !SAVE && fast_on && a.E < 16 * nb;
 #define CE_BF3(NB_)                                                                                        \
     do {                                                                                                   \
-      hipLaunchKernelGGL((ce_presplit_kernel<NB_>), dim3(pg), dim3(256), 0, s, a.V, a.E, a.W, a.vec, Wp);  \
+      if constexpr (!GRAD && !SAVE) {                                                                      \
+        if (fast) {                                                                                        \
+          hipLaunchKernelGGL((ce_presplit_kernel<NB_>), dim3(pg), dim3(256), 0, s, a.V, a.E, a.W, a.vec, Wp, \
+                             1.4426950408889634f, a.bias);                                                 \
+          CVAE_LAUNCH_CHECK("ce_presplit_kernel");                                                         \
+          hipLaunchKernelGGL((ce_core_bf3_kernel<NB_, false, false, true>), grid, block, 0, s, a, Wp);      \
+          break;                                                                                           \
+        }                                                                                                  \
+      }                                                                                                    \
+      hipLaunchKernelGGL((ce_presplit_kernel<NB_>), dim3(pg), dim3(256), 0, s, a.V, a.E, a.W, a.vec, Wp, 1.f, nullptr);  \
       CVAE_LAUNCH_CHECK("ce_presplit_kernel");                                                             \
       hipLaunchKernelGGL((ce_core_bf3_kernel<NB_, GRAD, SAVE>), grid, block, 0, s, a, Wp);                 \
     } while (0)

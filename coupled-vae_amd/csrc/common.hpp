@@ -9,7 +9,7 @@
 // -DCVAE_TIMING_BUILD, and every object compiled that way flips the sign of cvae_version(), so that the Python
 // binding (and tests/test_abi_and_host.py) refuse such a library unless CVAE_ALLOW_TIMING_BUILD=1.
 #if !defined(CVAE_TIMING_BUILD) && \
-    (defined(CE_EXP_NOLOAD) || defined(CE_EXP_NOLDS) || defined(CE_EXP_NOEPI) || \
+    (defined(CE_EXP_NOLOAD) || defined(CE_EXP_NOLDS) || defined(CE_EXP_NOEPI) || defined(CE_EXP_STAMPS) || \
      (defined(GW_EXP_NOSPLIT) && GW_EXP_NOSPLIT) || (defined(GW_EXP_NOMFMA) && GW_EXP_NOMFMA) || \
      (defined(GW_EXP_NOLOAD) && GW_EXP_NOLOAD) || (defined(GW_EXP_NOLDS) && GW_EXP_NOLDS) || \
      (defined(RB_EXP_NOSPLIT) && RB_EXP_NOSPLIT) || (defined(RB_EXP_NOEPI) && RB_EXP_NOEPI) || \

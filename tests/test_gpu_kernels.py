@@ -424,6 +424,27 @@ def test_projce_forward_backward(dev, shape):
     assert rel(lg, O.decoder_logits(P, 'D.', f64)) < 2e-5
 
 
+@pytest.mark.parametrize('V', [33, 34, 40, 47, 63, 64, 65, 1025])
+def test_projce_eval_form_pad_columns(dev, V):
+    """The evaluation form of the CE core (ce_core_bf3_kernel<.., FAST>: base-2 logits, the bias riding in the free K
+    slot of W's image, columns past V at -1e30 instead of a mask, its maximum taken by inline asm on the MFMA result)
+    at vocabulary sizes that leave 0 .. 31 padded columns in the last 32-column tile, against fp64: a last tile with
+    few real columns is where a too-early read of the accumulators showed."""
+    from cvae_amd import ops
+    T, R, E = 2, 37, 200
+    g = torch.Generator().manual_seed(V)
+    final = torch.tanh(torch.randn(T, R, E, generator=g))
+    W, b = torch.randn(V, E, generator=g) * 0.1, torch.randn(V, generator=g) * 0.1
+    eos = torch.randint(1, V, (R, T), generator=g)
+    eos[0, 0] = V - 1
+    logits = final.double() @ W.double().t() + b.double()
+    ref = (torch.logsumexp(logits, -1) - logits.gather(-1, eos.t().unsqueeze(-1)).squeeze(-1)).sum(0)
+    with torch.no_grad():
+        got = ops.proj_ce(final.to(dev), W.to(dev), b.to(dev), eos.to(dev), 0)
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < 2e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(9, 5, 16, 50), (30, 32, 200, 2100), (41, 32, 200, 10002), (64, 32, 200, 20000)])
 def test_projce_pair_matches_oracle_and_single(dev, shape):
