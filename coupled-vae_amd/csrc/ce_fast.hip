@@ -396,10 +396,11 @@ __global__ __launch_bounds__(256) void ce_presplit_kernel(int V, int E, const fl
 }
 
 // FAST (the evaluation launch: no GRAD, no SAVE, E < 16 NB): W's image is pre-scaled by log2 e and carries the bias
-// in K slot E (ce_presplit_kernel), so a tile's epilogue is max / subtract / v_exp_f32 / add per logit and nothing
-// else -- no bias add, no -inf masking, no multiply, and the target's logit is looked for only in the tile that holds
-// it.  The kernel's two waves per SIMD keep the vector issue port as busy as the matrix pipe: the epilogue's
-// instruction count is what its speed hangs on.  (m, target logit) go back to natural units when they are stored.
+// in K slot E (ce_presplit_kernel), so a tile's epilogue is max / subtract / v_exp_f32 / add per logit plus the
+// target pick -- no bias add, no -inf masking, no multiply (183 -> ~125 vector instructions per tile and wave).
+// (m, target logit) go back to natural units when they are stored.  Worth 2-6 % of the launch: the kernel runs at
+// 1.81-1.87 GHz (in-kernel clock, CE_EXP_STAMPS) with the matrix pipe ~65 % busy, and cycles saved come back partly
+// as clock.
 #ifdef CE_EXP_STAMPS
 #define CE_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sacc_[k] += (unsigned)(now_ - tprev_); tprev_ = now_; } while (0)
 #else
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
   auto stage_store = [&](int buf) {
     if (!FAST && tid < CE_TN) Bt[buf][tid] = bst;
   };
+
 
   for (int item = blockIdx.x; item < rb * nsplit; item += gridDim.x) {
     const int sp = item % nsplit, rbi = item / nsplit;
@@ -566,7 +568,10 @@ __global__ __launch_bounds__(256, 2) void ce_core_bf3_kernel(CeArgs p, const bf1
         for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(acc[r] - mn);
         s = sum;
         m = mn;
-        if (__builtin_amdgcn_ballot_w64((unsigned)(tg - n0) < (unsigned)CE_TN) != 0) {  // some row's target is in this tile
+        // (no "is any row's target in this tile" branch around this: it saved the 34 instructions on 19 tiles of 20, but
+        // the blocks of an XCD then drifted apart along the vocabulary and W's tiles stopped being shared in L2 --
+        // 42 GB instead of 9 GB fetched from the fabric per launch, at the same speed)
+        {
           const int jt = tg - n0 - 4 * lhi;
 #pragma unroll
           for (int r = 0; r < 16; ++r)

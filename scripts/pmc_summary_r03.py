@@ -17,8 +17,9 @@ import json
 import sys
 
 KEYS = collections.OrderedDict([
-    ('ce_core_forward_eval_launch', lambda n: 'ce_core_bf3_kernel<' in n and n.split('ce_core_bf3_kernel<')[1].split('>')[0].replace(' ', '').endswith('false,false')),
-    ('ce_core_train_forward', lambda n: 'ce_core_bf3_kernel<' in n and n.split('ce_core_bf3_kernel<')[1].split('>')[0].replace(' ', '').endswith('false,true')),
+    # template arguments <NB, GRAD, SAVE[, FAST]>: the evaluation launch is GRAD = SAVE = false, the training forward SAVE = true
+    ('ce_core_forward_eval_launch', lambda n: 'ce_core_bf3_kernel<' in n and n.split('ce_core_bf3_kernel<')[1].split('>')[0].replace(' ', '').split(',')[1:3] == ['false', 'false']),
+    ('ce_core_train_forward', lambda n: 'ce_core_bf3_kernel<' in n and n.split('ce_core_bf3_kernel<')[1].split('>')[0].replace(' ', '').split(',')[1:3] == ['false', 'true']),
     ('clip_adam_kernel', lambda n: 'clip_adam_kernel' in n),
     ('ce_grad_from_logits_kernel', lambda n: 'ce_grad_from_logits_kernel' in n),
     ('iw_reduce_kernel', lambda n: 'iw_reduce_kernel' in n),
