@@ -220,13 +220,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(TiledArgs p) { gemm_nt_
 typedef __bf16 nt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float nt_f32x8 __attribute__((ext_vector_type(8)));
 constexpr int NTB_BK = 32;
+// Tile of this workgroup.  With two column tiles (the decoders' W_c product: N = 200) the pair that shares 128 rows of A
+// is placed 8 workgroups apart -- consecutive workgroups go round the 8 XCDs, each with its own L2 -- so the second
+// read of those rows (3 GB per evaluation batch) is an L2 hit instead of a second trip to HBM.
+__device__ __forceinline__ void nt_tile_xy(int& bx, int& by) {
+  bx = blockIdx.x; by = blockIdx.y;
+  if (gridDim.x == 2) {
+    const int P = gridDim.y, L = blockIdx.x + 2 * blockIdx.y, full = (P / 8) * 16;
+    if (L < full) {
+      const int r = L & 15;
+      bx = r >> 3; by = (L >> 4) * 8 + (r & 7);
+    } else {
+      const int rem = P - (P / 8) * 8, r = L - full;
+      bx = r / rem; by = (P / 8) * 8 + r % rem;
+    }
+  }
+}
 __device__ __forceinline__ void gemm_nt_bf3_body(const TiledArgs& p) {
   constexpr int A_SL = 128 * 4, B_SL = 128 * 4, BUF_SL = 2 * A_SL + 2 * B_SL;   // slots: [A hi][A lo][B hi][B lo]
   extern __shared__ __attribute__((aligned(16))) float nt_smem[];
   nt_bf16x8* sm = reinterpret_cast<nt_bf16x8*>(nt_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  int bx, by;
+  nt_tile_xy(bx, by);
+  const int m0 = by * 128, n0 = bx * 128;
   const float* __restrict__ gA = p.A;
   const float* __restrict__ gB = p.B;
   long oa[2], ob[2];
@@ -372,7 +390,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_batched_kernel(TiledArgs p, Ti
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf3_batched_kernel(TiledArgs p, TiledBatch b) {
   p.M = b.m[blockIdx.z];
-  if ((int)blockIdx.y * 128 >= p.M) return;
+  int bx, by;
+  nt_tile_xy(bx, by);
+  if (by * 128 >= p.M) return;
   p.A += (long)blockIdx.z * b.sA;
   p.C += (long)blockIdx.z * b.sC;
   gemm_nt_bf3_body(p);

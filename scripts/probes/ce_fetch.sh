@@ -8,6 +8,6 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] == 'FETCH_SIZE': agg[r['Kernel_Name'][:60]].append(float(r['Counter_Value']))
 for k, v in agg.items():
-    if 'ce_core' in k: print(sys.argv[2], k, len(v), 'launches, fetch per launch (GB):', ' '.join('%.2f' % (x * 2048 / 1e9) for x in v))
+    if 'ce_core' in k or 'gemm_nt_bf3_batched' in k: print(sys.argv[2], k, len(v), 'launches, fetch per launch (GB):', ' '.join('%.2f' % (x * 2048 / 1e9) for x in v))
 PY
 rm -f $R/gpurun_out/ce_fetch_$1/f_counter_collection.csv
