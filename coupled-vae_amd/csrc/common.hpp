@@ -293,8 +293,8 @@ size_t rnn_large_image_bytes(int R, int H);
 long rnn_large_image_lo(int R, int H);          // elements from the hi half to the lo half
 int launch_rnn_large_split(const float* h, int rows, int H, void* img, long img_lo, hipStream_t s);
 size_t rnn_large_wimg_bytes(int H);
-int launch_rnn_large_wimg(const float* W_hh, int H, void* wimg, hipStream_t s);       // W_hh -> the kernel's fragment image
-int launch_rnn_large_wreg_step(int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
+int launch_rnn_large_wimg(int cell, const float* W_hh, int H, void* wimg, hipStream_t s);       // W_hh -> the kernel's fragment image
+int launch_rnn_large_wreg_step(int cell, int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
                                const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
                                float* c_out, const void* img_in, void* img_out, long img_lo, hipStream_t s);
 int launch_rnn_large_step(int cell, int live, int H, const float* h_prev, const float* c_prev, const float* W_hh,

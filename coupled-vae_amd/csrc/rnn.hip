@@ -130,10 +130,10 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
         img[0] = static_cast<char*>(base);
         img[1] = img[0] + one;
         CVAE_TRY(lib_scratch(LS_W_IMAGE, s, rnn_large_wimg_bytes(a.H), &wimg));
-        CVAE_TRY(launch_rnn_large_wimg(a.W_hh, a.H, wimg, s));
+        CVAE_TRY(launch_rnn_large_wimg(a.cell, a.W_hh, a.H, wimg, s));
       }
       if (!img_valid) CVAE_TRY(launch_rnn_large_split(k.h_prev, live, a.H, img[i & 1], img_lo, s));
-      CVAE_TRY(launch_rnn_large_wreg_step(live, a.H, k.h_prev, k.c_prev, wimg, a.b_hh, k.xproj, a.xmod, xdiv, a.xadd,
+      CVAE_TRY(launch_rnn_large_wreg_step(a.cell, live, a.H, k.h_prev, k.c_prev, wimg, a.b_hh, k.xproj, a.xmod, xdiv, a.xadd,
                                           k.h_out, k.c_out, img[i & 1], img[(i + 1) & 1], img_lo, s));
       img_valid = true;
       continue;

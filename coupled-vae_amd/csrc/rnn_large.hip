@@ -472,9 +472,10 @@ __global__ __launch_bounds__(256) void rnn_large_split_kernel(long n8, const flo
 
 // W_hh -> the B fragments of rnn_large_wreg_kernel, in the order its waves load them (once per decoder call: the
 // step kernel then fills its registers with 1 KB-contiguous loads instead of re-splitting its share at every step)
-__global__ __launch_bounds__(WR_THREADS) void rnn_large_wimg_kernel(int H, const float* __restrict__ W_hh, i32x4* __restrict__ wimg) {
+__global__ __launch_bounds__(WR_THREADS) void rnn_large_wimg_kernel(int H, int G, const float* __restrict__ W_hh, i32x4* __restrict__ wimg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int gate = wave & 3, uh = wave >> 2, cg = blockIdx.x, nkb = H / 32;
+  if (gate >= G) return;                                      // GRU: the waves of a fourth gate hold nothing
   const float* wrow = W_hh + (long)(gate * H + cg * 32 + 16 * uh + l15) * H + 8 * kq;
   i32x4* dst = wimg + (size_t)(cg * 8 + wave) * nkb * 2 * 64 + lane;
   for (int kb = 0; kb < nkb; ++kb) {
@@ -485,10 +486,11 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wimg_kernel(int H, const
   }
 }
 
-template <int NKB, bool XADD>                                 // K blocks of 32: H = 32 NKB
+template <int NKB, bool XADD, int CELL>                       // K blocks of 32: H = 32 NKB
 __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs w) {
   const RnnLargeArgs& p = w.a;
-  constexpr int H = NKB * 32, GH = 4 * H, SLOTS = H / 8;      // 16-byte slots per row of an image
+  constexpr int G = CELL == CELL_GRU ? 3 : 4;                 // GRU: the two waves of "gate 3" multiply nothing (they stage and run cells)
+  constexpr int H = NKB * 32, GH = G * H, SLOTS = H / 8;      // 16-byte slots per row of an image
   constexpr int IMG = WR_ROWS * SLOTS;                        // slots of one image (hi or lo) of a 16-row tile
   constexpr int SEGS = IMG / 64;                              // DMA pieces (64 slots = 1 KB) per image
   constexpr int PW = 2 * SEGS / 8;                            // ... per wave and tile: 4 (H 512), 2 (H 256)
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
   // from the image rnn_large_wimg_kernel wrote
   i32x4 bh[NKB], bl[NKB];
   {
-    const i32x4* src = w.wimg + (size_t)(cg * 8 + wave_u) * NKB * 2 * 64 + lane;
+    const i32x4* src = w.wimg + (size_t)(cg * 8 + wave_u) * NKB * 2 * 64 + lane;     // (GRU's gate-3 waves: an unwritten slice of the image, never multiplied)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #if WR_EXP_NOB
@@ -553,9 +555,9 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+a"(bh[kb]), "+a"(bl[kb]));       // from here on accumulator-file tuples
   }
-  float bq[4];
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bq[g] = p.b_hh[g * H + u];
+  for (int g = 0; g < G; ++g) bq[g] = p.b_hh[g * H + u];
 
   // The cell's row of a tile: m0 + 2 wave + lhi, unit u.  Its operands are addressed as (scalar base) + (32-bit lane
   // offset): one multiply-add per array instead of 64-bit arithmetic per load -- the kernel's vector issue is as busy
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
   const float inv_xdiv = 1.f / (float)p.xdiv;
   const char* xadd_b = reinterpret_cast<const char*>(p.xadd);
   const char* xproj_b = reinterpret_cast<const char*>(p.xproj);
-  const char* cprev_b = reinterpret_cast<const char*>(p.c_prev);
+  const char* cprev_b = reinterpret_cast<const char*>(CELL == CELL_LSTM ? p.c_prev : p.h_prev);   // the cell's state operand: c (LSTM), h (GRU)
   auto ldf = [](const char* base, unsigned off) { return *reinterpret_cast<const float*>(base + off); };
   float xa[4], cp;
   auto cell_prefetch = [&](int n) {
@@ -574,10 +576,12 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
     for (int g = 0; g < 4; ++g) xa[g] = 0.1f * g + 1e-6f * mc;
     cp = 0.25f;
 #else
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xa[g] = 0.f;
     if constexpr (XADD) {
       const unsigned o = (unsigned)(mc * GH + u) * 4u;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xa[g] = ldf(xadd_b, o + g * (H * 4));
+      for (int g = 0; g < G; ++g) xa[g] = ldf(xadd_b, o + g * (H * 4));
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) xa[g] = 0.f;
@@ -610,17 +614,25 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
   char* ihi_b = reinterpret_cast<char*>(w.img_out);
   char* ilo_b = reinterpret_cast<char*>(w.img_out + w.img_lo);
   auto cell_finish = [&]() {
-    const float ig = sigmoid_fast(pre[0]);
-    const float fg = sigmoid_fast(pre[1]);
-    const float gg = tanh_fast(pre[2]);
-    const float og = sigmoid_fast(pre[3]);
-    const float cnew = fg * cprev + ig * gg;
-    const float hnew = og * tanh_fast(cnew);
+    float hnew, cnew = 0.f;
+    if constexpr (CELL == CELL_LSTM) {
+      const float ig = sigmoid_fast(pre[0]);
+      const float fg = sigmoid_fast(pre[1]);
+      const float gg = tanh_fast(pre[2]);
+      const float og = sigmoid_fast(pre[3]);
+      cnew = fg * cprev + ig * gg;
+      hnew = og * tanh_fast(cnew);
+    } else {                                                  // pre = (r, z, x-side of n, h-side of n); cprev = h
+      const float rgate = sigmoid_fast(pre[0]);
+      const float zg = sigmoid_fast(pre[1]);
+      const float nn = tanh_fast(pre[2] + rgate * pre[3]);
+      hnew = (1.f - zg) * nn + zg * cprev;
+    }
     const __bf16 hh = (__bf16)hnew;
     const __bf16 hl = (__bf16)(hnew - (float)hh);
     if (vprev) {
       *reinterpret_cast<float*>(hout_b + oprev) = hnew;
-      *reinterpret_cast<float*>(cout_b + oprev) = cnew;
+      if constexpr (CELL == CELL_LSTM) *reinterpret_cast<float*>(cout_b + oprev) = cnew;
       *reinterpret_cast<__bf16*>(ihi_b + (oprev >> 1)) = hh;
       *reinterpret_cast<__bf16*>(ilo_b + (oprev >> 1)) = hl;
     }
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
         q += rem >= p.xdiv ? 1 : (rem < 0 ? -1 : 0);
         const unsigned o = (unsigned)(q * GH + u) * 4u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xq[g] = ldf(xproj_b, o + g * (H * 4));
+        for (int g = 0; g < G; ++g) xq[g] = ldf(xproj_b, o + g * (H * 4));
       }
 #endif
       if (kb == PW + 1) cell_prefetch(n + 1);
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
       acc0[kb & 3] += __builtin_bit_cast(f32x4, ah)[0] + __builtin_bit_cast(f32x4, al)[1];
       if (false)
 #endif
+      if (G == 4 || (wave_u & 3) < G)                         // wave-uniform: GRU's gate-3 waves multiply nothing
       asm volatile("s_nop 1\n\t"
                    "v_mfma_f32_16x16x32_bf16 %0, %3, %6, %0\n\t"
                    "v_mfma_f32_16x16x32_bf16 %1, %4, %5, %1\n\t"
@@ -695,15 +708,24 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
 #endif
     // acc[r] = gate `gate` of row 4 kq + r, unit 16 uh + l15
     const int xoff = (n & 1) * XSZ;
+    if (G == 4 || gate < G) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xw[xoff + r * 32] = acc[r];
+      for (int r = 0; r < 4; ++r) xw[xoff + r * 32] = acc[r];
+    }
     // one barrier per tile: X(n) complete; the other buffer's image landed (hipcc drains an LDS-DMA in flight at a
     // barrier); this buffer's reads over.  X is double-buffered: X(n+2) is written after barrier n+1, which every
     // wave passes only after it has read X(n).
     __syncthreads();
     WR_STAMP(2);
+    if constexpr (CELL == CELL_LSTM) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = xr[xoff + g * WR_ROWS * 32] + ((x[g] + xq[g]) + bq[g]);
+      for (int g = 0; g < 4; ++g) pre[g] = xr[xoff + g * WR_ROWS * 32] + ((x[g] + xq[g]) + bq[g]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) pre[g] = xr[xoff + g * WR_ROWS * 32] + ((x[g] + xq[g]) + bq[g]);
+      pre[2] = x[2] + xq[2];
+      pre[3] = xr[xoff + 2 * WR_ROWS * 32] + bq[2];
+    }
     cprev = cc;
     oprev = (unsigned)(mc * H + u) * 4u;
     vprev = m < p.live;
@@ -740,7 +762,7 @@ int rnn_large_wreg_set(int min_rows) {
 // (xmod, xdiv): the kernel takes row r's x-side row as r / xdiv, so every live row must lie below xdiv * xmod; its
 // 32-bit byte offsets need live * 4H * 4 < 2^32
 bool rnn_large_wreg_supported(int cell, int H, int live, int xmod, int xdiv, const float* h, const float* W_hh) {
-  return split_bf16_enabled() && cell == CELL_LSTM && (H == 512 || H == 256) && live >= wreg_min_rows() &&
+  return split_bf16_enabled() && (cell == CELL_LSTM || cell == CELL_GRU) && (H == 512 || H == 256) && live >= wreg_min_rows() &&
          (long)live <= (long)xmod * xdiv && (long)live * 16 * H < (1L << 32) &&
          aligned16(h) && aligned16(W_hh) && persistent_grid_blocks() / 2 / (H / 32) >= 8;
 }
@@ -761,21 +783,23 @@ int launch_rnn_large_split(const float* h, int rows, int H, void* img, long img_
 size_t rnn_large_wimg_bytes(int H) { return (size_t)4 * H * H * 4; }      // 4H x H (hi, lo) bf16
 
 // W_hh ([4H, H] fp32) -> the step kernel's fragment image
-int launch_rnn_large_wimg(const float* W_hh, int H, void* wimg, hipStream_t s) {
+int launch_rnn_large_wimg(int cell, const float* W_hh, int H, void* wimg, hipStream_t s) {
   CVAE_REQUIRE(W_hh && wimg && (H == 512 || H == 256) && aligned16(W_hh) && aligned16(wimg), "rnn_large_wimg: bad argument");
-  hipLaunchKernelGGL(rnn_large_wimg_kernel, dim3(H / 32), dim3(WR_THREADS), 0, s, H, W_hh, static_cast<i32x4*>(wimg));
+  hipLaunchKernelGGL(rnn_large_wimg_kernel, dim3(H / 32), dim3(WR_THREADS), 0, s, H, cell == CELL_GRU ? 3 : 4, W_hh,
+                     static_cast<i32x4*>(wimg));
   CVAE_LAUNCH_CHECK("rnn_large_wimg_kernel");
   return 0;
 }
 
 // one step of rows [0, live) on the weights-in-registers kernel; img_in = split image of h_prev, img_out receives h_out's;
 // wimg = launch_rnn_large_wimg's image of W_hh
-int launch_rnn_large_wreg_step(int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
+int launch_rnn_large_wreg_step(int cell, int live, int H, const float* h_prev, const float* c_prev, const void* wimg,
                                const float* b_hh, const float* xproj, int xmod, int xdiv, const float* xadd, float* h_out,
                                float* c_out, const void* img_in, void* img_out, long img_lo, hipStream_t s) {
   if (live <= 0) return 0;
-  CVAE_REQUIRE(h_prev && c_prev && wimg && b_hh && xproj && h_out && c_out && img_in && img_out && xmod > 0 && xdiv > 0,
+  CVAE_REQUIRE(h_prev && wimg && b_hh && xproj && h_out && img_in && img_out && xmod > 0 && xdiv > 0,
                "rnn_large_wreg_step: null operand");
+  CVAE_REQUIRE(cell == CELL_GRU || (cell == CELL_LSTM && c_prev && c_out), "rnn_large_wreg_step: bad cell, or LSTM without c");
   CVAE_REQUIRE(H == 512 || H == 256, "rnn_large_wreg_step: H=%d (256 or 512)", H);
   CVAE_REQUIRE(aligned16(img_in) && aligned16(img_out) && img_lo % 8 == 0 && img_lo >= rnn_large_image_lo(live, H),
                "rnn_large_wreg_step: image misaligned or too small");
@@ -785,24 +809,34 @@ int launch_rnn_large_wreg_step(int live, int H, const float* h_prev, const float
   RnnWregArgs a = {{h_prev, c_prev, nullptr, b_hh, xproj, xadd, h_out, c_out, live, H, xmod, xdiv},
                    static_cast<const __bf16*>(img_in), static_cast<__bf16*>(img_out), img_lo, nrg,
                    static_cast<const i32x4*>(wimg)};
-  ProfScope prof(PK_RNN_LARGE, s, 2.0 * live * 4 * H * (double)H);
+  ProfScope prof(PK_RNN_LARGE, s, 2.0 * live * (cell == CELL_GRU ? 3 : 4) * H * (double)H);
   const dim3 gridw(ncg * nrg);
   const size_t ldsw = (size_t)4 * WR_ROWS * (H / 8) * 16 + 2 * 4 * WR_ROWS * 32 * sizeof(float);     // 80 KB (H 512) / 48 KB
   static bool attrw = false;
   if (!attrw) {
-    const void* fs[4] = {reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, true>),
-                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, false>),
-                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, true>),
-                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, false>)};
+    const void* fs[8] = {reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, true, CELL_LSTM>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, false, CELL_LSTM>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, true, CELL_LSTM>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, false, CELL_LSTM>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, true, CELL_GRU>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<16, false, CELL_GRU>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, true, CELL_GRU>),
+                         reinterpret_cast<const void*>(&rnn_large_wreg_kernel<8, false, CELL_GRU>)};
     for (const void* f : fs)
       CVAE_TRY(check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "rnn_large wreg LDS attribute"));
     attrw = true;
   }
   const dim3 blockw(WR_THREADS);
-  if (H == 512 && xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, true>), gridw, blockw, ldsw, s, a);
-  else if (H == 512) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, false>), gridw, blockw, ldsw, s, a);
-  else if (xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<8, true>), gridw, blockw, ldsw, s, a);
-  else hipLaunchKernelGGL((rnn_large_wreg_kernel<8, false>), gridw, blockw, ldsw, s, a);
+#define WR_LAUNCH(CELL_)                                                                                         \
+  do {                                                                                                           \
+    if (H == 512 && xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, true, CELL_>), gridw, blockw, ldsw, s, a);   \
+    else if (H == 512) hipLaunchKernelGGL((rnn_large_wreg_kernel<16, false, CELL_>), gridw, blockw, ldsw, s, a);    \
+    else if (xadd) hipLaunchKernelGGL((rnn_large_wreg_kernel<8, true, CELL_>), gridw, blockw, ldsw, s, a);          \
+    else hipLaunchKernelGGL((rnn_large_wreg_kernel<8, false, CELL_>), gridw, blockw, ldsw, s, a);                   \
+  } while (0)
+  if (cell == CELL_GRU) WR_LAUNCH(CELL_GRU);
+  else WR_LAUNCH(CELL_LSTM);
+#undef WR_LAUNCH
   CVAE_LAUNCH_CHECK("rnn_large_wreg_kernel");
   return 0;
 }

@@ -400,7 +400,7 @@ int cvae_persist_status_import(const float* src, void* stream);
 /* Runtime form of CVAE_PERSISTENT_RNN: 0 = recurrences run on the per-timestep kernels from the next call on (what a
  * caller switches to after a time-out, without restarting); returns the previous setting. */
 int cvae_persistent_rnn(int on);
-/* Many-row recurrent step (IW evaluation, LSTM, H = 256 / 512): live-row count from which the weights-in-registers
+/* Many-row recurrent step (IW evaluation, LSTM / GRU, H = 256 / 512): live-row count from which the weights-in-registers
  * kernel replaces the 128-row-tile one (default 64; env CVAE_RNN_LARGE_WREG_MIN; a huge value = never; negative =
  * query only).  Returns the previous value.  A tuning / test switch with no counterpart in the reference. */
 int cvae_rnn_large_wreg(int min_rows);

@@ -11,7 +11,9 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 B, E, V, T = 32, 200, 2000, 24
 g = torch.Generator().manual_seed(0)
 r = lambda *s: (torch.randn(*s, generator=g) * 0.1).to(dev)
-w = [r(4 * Hd, 2 * E), r(4 * Hd, Hd), r(4 * Hd), r(4 * Hd), r(E, Hd), r(E)]
+CELL = ops.GRU if os.environ.get('CELL', 'lstm') == 'gru' else ops.LSTM
+G = 3 if CELL == ops.GRU else 4
+w = [r(G * Hd, 2 * E), r(G * Hd, Hd), r(G * Hd), r(G * Hd), r(E, Hd), r(E)]
 emb, init = r(V, E), r(B * K, E)
 go = torch.randint(4, V, (B, T), generator=g).to(dev)
 for name, live in (('all live', torch.full((T,), B, dtype=torch.int32)),
@@ -20,10 +22,10 @@ for name, live in (('all live', torch.full((T,), B, dtype=torch.int32)),
     for mode, mn in (('tile128', 1 << 30), ('wreg', 64)):
         _lib.query('cvae_rnn_large_wreg', mn)
         for _ in range(2):
-            f = ops.decoder_sorted(ops.LSTM, init, go, live, emb, w)
+            f = ops.decoder_sorted(CELL, init, go, live, emb, w)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
-            f = ops.decoder_sorted(ops.LSTM, init, go, live, emb, w)
+            f = ops.decoder_sorted(CELL, init, go, live, emb, w)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
         out[mode] = f
         print('%-9s %-8s decoder %.2f ms (%.1f us per step)' % (name, mode, dt * 1e3, dt / T * 1e6), flush=True)

@@ -347,9 +347,10 @@ def test_decoder_forward_sorted(dev, cell, shape):
     assert torch.equal(tgt, eos.t()[:, :, None].expand(T, B, K))
 
 
+@pytest.mark.parametrize('cell', ['lstm', 'gru'])
 @pytest.mark.parametrize('shape', [(5, 7, 24, 256, 50, 53), (9, 6, 40, 512, 60, 37), (3, 4, 16, 512, 30, 700)])
-def test_decoder_sorted_weights_in_registers(dev, shape):
-    """The many-row LSTM step with W_hh resident in registers (rnn_large_wreg_kernel: h read as a bf16 (hi, lo) image
+def test_decoder_sorted_weights_in_registers(dev, shape, cell):
+    """The many-row LSTM / GRU step with W_hh resident in registers (rnn_large_wreg_kernel: h read as a bf16 (hi, lo) image
     by LDS-DMA, the cell one tile behind) against the 128-row-tile kernel on the same call -- cvae_rnn_large_wreg()
     switches between them at run time -- with live prefixes that are not multiples of the 16-row tile, at both hidden
     sizes the kernel takes; skipped rows stay zero.  (Both kernels form bf16x3 products, in different summation
@@ -363,7 +364,8 @@ def test_decoder_sorted_weights_in_registers(dev, shape):
     lens = torch.sort(lens, descending=True).values
     go = torch.randint(1, V, (B, T), generator=g).to(dev)
     emb = torch.randn(V, E, generator=g).to(dev)
-    ws = _rnn_params('lstm', 2 * E, Hd, False, 4)
+    ws = _rnn_params(cell, 2 * E, Hd, False, 4)
+    c = ops.GRU if cell == 'gru' else ops.LSTM
     k = 1.0 / math.sqrt(Hd)
     W_c, b_c = (torch.rand(E, Hd, generator=g) * 2 - 1) * k, (torch.rand(E, generator=g) * 2 - 1) * k
     w_d = [w.to(dev) for w in ws + [W_c, b_c]]
@@ -371,10 +373,10 @@ def test_decoder_sorted_weights_in_registers(dev, shape):
     live_sent = (lens[None, :] > torch.arange(T)[:, None]).sum(1).to(torch.int32)
     prev = _lib.query('cvae_rnn_large_wreg', 1 << 30)
     try:
-        want = ops.decoder_sorted(ops.LSTM, init_s, go, live_sent, emb, w_d)
+        want = ops.decoder_sorted(c, init_s, go, live_sent, emb, w_d)
         _lib.query('cvae_rnn_large_wreg', 1)
-        got = ops.decoder_sorted(ops.LSTM, init_s, go, live_sent, emb, w_d)
-        again = ops.decoder_sorted(ops.LSTM, init_s, go, live_sent, emb, w_d)
+        got = ops.decoder_sorted(c, init_s, go, live_sent, emb, w_d)
+        again = ops.decoder_sorted(c, init_s, go, live_sent, emb, w_d)
     finally:
         _lib.query('cvae_rnn_large_wreg', prev)
     assert torch.equal(got, again)                                        # no dependence on what the scratch images held
