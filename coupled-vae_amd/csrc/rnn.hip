@@ -115,7 +115,8 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
   char* img[2] = {nullptr, nullptr};
   void* wimg = nullptr;                   // W_hh as that kernel's register fragments (written once per call)
   const long img_lo = rnn_large_image_lo(a.R, a.H);
-  bool img_valid = false;                 // img[i & 1] holds the split of step i's h_prev
+  bool img_valid = false;                 // img[i & 1] holds the split of step i's h_prev ...
+  int img_rows = 0;                       // ... for its first img_rows rows
   for (int i = 0; i < a.T; ++i) {
     SkinnyArgs k;
     rnn_forward_step_args(a, i, k);
@@ -132,7 +133,9 @@ static int rnn_forward_large(const RnnFwd& a, hipStream_t s) {
         CVAE_TRY(lib_scratch(LS_W_IMAGE, s, rnn_large_wimg_bytes(a.H), &wimg));
         CVAE_TRY(launch_rnn_large_wimg(a.cell, a.W_hh, a.H, wimg, s));
       }
-      if (!img_valid) CVAE_TRY(launch_rnn_large_split(k.h_prev, live, a.H, img[i & 1], img_lo, s));
+      // (a live prefix that grows again reads rows the previous step's cell did not write: split those from h_prev)
+      if (!img_valid || live > img_rows) CVAE_TRY(launch_rnn_large_split(k.h_prev, live, a.H, img[i & 1], img_lo, s));
+      img_rows = live;
       CVAE_TRY(launch_rnn_large_wreg_step(a.cell, live, a.H, k.h_prev, k.c_prev, wimg, a.b_hh, k.xproj, a.xmod, xdiv, a.xadd,
                                           k.h_out, k.c_out, img[i & 1], img[(i + 1) & 1], img_lo, s));
       img_valid = true;
