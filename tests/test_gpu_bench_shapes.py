@@ -86,8 +86,9 @@ def test_train_step_vs_oracle_scaleup_share(dev, cell):
 @pytest.mark.parametrize('shape,cell,B,K', [('yelp', 'lstm', 16, 20), ('yelp', 'gru', 16, 20), ('yelp', 'lstm', 32, 40),
                                             ('scaleup', 'lstm', 8, 40)])
 def test_iw_nll_vs_oracle_bench_shapes(dev, shape, cell, B, K):
-    """IW-NLL with B*K > 256 rows at Hd = 512 (and 2048): the many-row recurrence (rnn_large_step_kernel),
-    the batched W_c product and the CE kernel on sentence-major sorted rows, against the oracle."""
+    """IW-NLL with B*K > 256 rows at Hd = 512 (and 2048): the many-row recurrence (rnn_large_wreg_kernel at Hd = 512,
+    both cells -- the default from 64 live rows; rnn_large_step_kernel below that and at Hd = 2048), the batched W_c
+    product and the CE kernel's evaluation form on sentence-major sorted rows, against the oracle."""
     from cvae_amd import modules, data, harness
     s = dict(data.SHAPES[shape])
     s['V'] = 2000
