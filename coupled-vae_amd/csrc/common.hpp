@@ -11,7 +11,7 @@
 #if !defined(CVAE_TIMING_BUILD) && \
     (defined(CE_EXP_NOLOAD) || defined(CE_EXP_NOLDS) || defined(CE_EXP_NOEPI) || defined(CE_EXP_STAMPS) || \
      (defined(GW_EXP_NOSPLIT) && GW_EXP_NOSPLIT) || (defined(GW_EXP_NOMFMA) && GW_EXP_NOMFMA) || \
-     (defined(GW_EXP_NOLOAD) && GW_EXP_NOLOAD) || (defined(GW_EXP_NOLDS) && GW_EXP_NOLDS) || \
+     (defined(GW_EXP_NOLOAD) && GW_EXP_NOLOAD) || (defined(GW_EXP_NOLDS) && GW_EXP_NOLDS) || (defined(GW_EXP_NOB) && GW_EXP_NOB) || \
      (defined(RB_EXP_NOSPLIT) && RB_EXP_NOSPLIT) || (defined(RB_EXP_NOEPI) && RB_EXP_NOEPI) || \
      (defined(RB_EXP_NOMFMA) && RB_EXP_NOMFMA) || (defined(WR_EXP_NOEPILOAD) && WR_EXP_NOEPILOAD) || \
      (defined(WR_EXP_NOSTAGELOAD) && WR_EXP_NOSTAGELOAD) || \

@@ -366,6 +366,9 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 #ifndef GW_EXP_NOLDS
 #define GW_EXP_NOLDS 0
 #endif
+#ifndef GW_EXP_NOB
+#define GW_EXP_NOB 0       // B tile fetched, split and stored for the first two chunks of an item only
+#endif
 __device__ __forceinline__ void gw_split(const f32x8 v, bf16x8 (&t)[3]) {
 #if GW_EXP_NOSPLIT
   union { f32x8 f; bf16x8 h[2]; } u;
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Batch batch) 
         }
       }
     };
+    bool do_b = true;      // (GW_EXP_NOB)
     auto store = [&](int buf, const float4 (&ra)[AKC ? 2 : 1], const float4 (&rt)[8]) {
       bf16x8* base = sm + buf * BUF_SL;
       if (AKC) {
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Batch batch) 
           for (int q = 0; q < 3; ++q) base[q * A_SL + sl] = t[q];
         }
       }
-      if (has_b) {
+      if (has_b && do_b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x8 v;
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Batch batch) 
           for (int kk = 0; kk < 8; ++kk) rt[kk] = *reinterpret_cast<const float4*>(fa + (long)(kb + kk) * p.lda);
         }
       }
-      if (has_b) {
+      if (has_b && do_b) {
         const int kb = k0 + 8 * b_kh;
         if (p.dev_bound == 2) {
           int ri[8];
@@ -635,6 +639,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_bf3_kernel(G224Batch batch) 
       store(0, ra_[0], rt_[0]);
       __syncthreads();
       for (int kt = 0; kt < nk; ++kt) {
+#if GW_EXP_NOB
+        do_b = kt < 1;
+#endif
         fetch(kt + 1, ra_[0], rt_[0]);
         compute(kt & 1);
 #if GW_EXP_NOLDS
