@@ -84,7 +84,7 @@ def test_train_step_vs_oracle_scaleup_share(dev, cell):
 
 
 @pytest.mark.parametrize('shape,cell,B,K', [('yelp', 'lstm', 16, 20), ('yelp', 'gru', 16, 20), ('yelp', 'lstm', 32, 40),
-                                            ('scaleup', 'lstm', 8, 40)])
+                                            ('ptb', 'lstm', 16, 20), ('ptb', 'gru', 16, 20), ('scaleup', 'lstm', 8, 40)])
 def test_iw_nll_vs_oracle_bench_shapes(dev, shape, cell, B, K):
     """IW-NLL with B*K > 256 rows at Hd = 512 (and 2048): the many-row recurrence (rnn_large_wreg_kernel at Hd = 512,
     both cells -- the default from 64 live rows; rnn_large_step_kernel below that and at Hd = 2048), the batched W_c
@@ -95,7 +95,7 @@ def test_iw_nll_vs_oracle_bench_shapes(dev, shape, cell, B, K):
     hp = harness.HParams(model='vae-couple', cell=cell, V=s['V'], E=s['E'], H=s['H'], Z=s['Z'])
     tr = harness.Trainer(hp, dev, seed=4)
     cap = 200 if shape == 'yelp' else 40
-    sents = data.synthetic_sentences(B, s['V'], s['mu'] if shape == 'yelp' else 3.0, s['sigma'], cap, seed=31)
+    sents = data.synthetic_sentences(B, s['V'], s['mu'] if shape == 'yelp' else 3.0, s['sigma'], cap, seed=31)    # ('ptb': Hd = 256)
     if shape == 'yelp':
         sents[2] = np.random.RandomState(5).randint(4, s['V'], size=200).astype(np.int64)
     c = data.Corpus(sents)
