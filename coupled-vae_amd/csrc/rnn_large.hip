@@ -680,7 +680,6 @@ __global__ __launch_bounds__(WR_THREADS) void rnn_large_wreg_kernel(RnnWregArgs 
       if (kb == PW + 3) cell_finish();                        // tile n-1
 #endif
       if (kb + WR_PF < NKB) {
-        constexpr int dummy = 0; (void)dummy;
         const int k2 = kb + WR_PF;
         fh[k2 % (WR_PF + 1)] = __builtin_bit_cast(i32x4, fr[k2 & 3][boff + 16 * (k2 >> 2)]);
         fl[k2 % (WR_PF + 1)] = __builtin_bit_cast(i32x4, fr[k2 & 3][boff + IMG + 16 * (k2 >> 2)]);
